@@ -1,0 +1,60 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, name)
+
+
+def golden_bytes(name):
+    with open(golden_path(name), "rb") as f:
+        return f.read()
+
+
+def golden_json(name):
+    with open(golden_path(name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def edge_vectors():
+    return golden_json("edge_vectors.json")
+
+
+@pytest.fixture(scope="session")
+def class_digests():
+    return golden_json("class_digests.json")
+
+
+def uncompressible_sequence():
+    """22 rows x 23 letters with no repeated digram: row k, column i (1-based) is
+    letter (k*i - 1) mod 23 -- the construction behind the table at
+    c/src/test/test-lzs.c:44-66 (23 is prime, so every row is a permutation)."""
+    return bytes(97 + (k * i - 1) % 23 for k in range(1, 23) for i in range(1, 24))
+
+
+def length_bits(repeated):
+    """Bit cost of the length field(s) of one match of `repeated` bytes
+    (c/src/test/test-lzs.c:73-87)."""
+    if repeated == 0:
+        return 0
+    if repeated == 1:
+        return 9
+    if repeated <= 4:
+        return 2
+    if repeated <= 7:
+        return 4
+    return ((repeated + 22) // 15) * 4
