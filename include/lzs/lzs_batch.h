@@ -1,0 +1,98 @@
+/*
+ * lzs/lzs_batch.h -- additive entry points of the MI355X build of liblzs: many
+ * independent blocks per call, host or device buffers.
+ *
+ * The reference has no batch interface: its unit of work is one call of
+ * lzs_compress()/lzs_decompress() (c/src/liblzs/lzs.h:218,229) per buffer, and the
+ * way to process many buffers is a loop of such calls (c/src/test/test-lzs.c:111-114,
+ * c/src/utils/lzs-compress.c:207).  Every function below is defined as exactly that
+ * loop -- block b of a batch produces the bytes and the length that one reference call
+ * on block b alone would -- executed by one GPU wavefront per block.
+ *
+ * All functions return LZS_OK (0) or a negative LZS_E_* code; lzs_last_error() gives
+ * the message of the calling thread's most recent failure.  Plain C types only.
+ */
+#ifndef LZS_MI355X_LZS_BATCH_H
+#define LZS_MI355X_LZS_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZS_OK            0
+#define LZS_E_NO_DEVICE  (-1)   /* no usable HIP device / runtime                      */
+#define LZS_E_HIP        (-2)   /* a HIP call failed (message in lzs_last_error())     */
+#define LZS_E_ARG        (-3)   /* invalid argument                                    */
+#define LZS_E_NOMEM      (-4)   /* device or host allocation failed                    */
+
+/* Largest single block (bytes) a kernel accepts. */
+#define LZS_BLOCK_MAX    (3u << 30)
+
+/* Message for the calling thread's most recent failure ("" if none). Never NULL. */
+const char *lzs_last_error(void);
+
+/* Human-readable description of the backend ("hip gfx950 ... 256 CUs ...") into buf.
+ * Returns LZS_OK, or LZS_E_NO_DEVICE when there is no device (buf then holds the reason). */
+int lzs_backend_info(char *buf, size_t cap);
+
+/*
+ * Device-pointer batch compression, asynchronous on `hip_stream`.
+ *
+ *   block b input  : d_in  + b * in_stride ,  length d_in_len ? d_in_len[b] : in_len
+ *   block b output : d_out + b * out_stride,  capacity out_cap (same rule as
+ *                    a_outBufferSize of lzs_compress(): the stream is cut there)
+ *   d_out_len[b]   : bytes written for block b
+ *
+ * Each block is an independent LZS stream with its own end marker, i.e. the result of
+ * lzs_compress(d_out + b*out_stride, out_cap, d_in + b*in_stride, len_b)
+ * (reference lzs-compression.c:249-467).  All pointers are device pointers;
+ * d_in_len may be NULL.  `hip_stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Fastest when d_in, in_stride are multiples of 16 and d_out,
+ * out_stride multiples of 4; any alignment is accepted.  No allocation, no
+ * synchronisation: safe to capture into a hipGraph.
+ */
+int lzs_compress_batch_device(void *d_out, size_t out_stride, size_t out_cap, uint32_t *d_out_len,
+                              const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                              size_t in_len, size_t nblocks, void *hip_stream);
+
+/*
+ * Device-pointer batch decompression, asynchronous on `hip_stream`; block b is
+ * lzs_decompress(d_out + b*out_stride, out_cap, d_in + b*in_stride, len_b)
+ * (reference lzs-decompression.c:156-412).  Arguments as above.
+ */
+int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, uint32_t *d_out_len,
+                                const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                                size_t in_len, size_t nblocks, void *hip_stream);
+
+/*
+ * Gather the variable-length results of a batch into one dense byte string:
+ * d_offsets[b] = sum of d_len[0..b) for b = 0..nblocks (nblocks+1 entries, uint64),
+ * d_dense[d_offsets[b] .. d_offsets[b+1]) = slot b's first d_len[b] bytes.
+ * d_dense must hold sum(d_len) bytes (at most nblocks*max len).  Concatenated
+ * independent streams are what the reference's file decompressor consumes
+ * (c/src/liblzs/lzs-decompression.c:564-576 realigns after each end marker).
+ * Asynchronous on `hip_stream`, no allocation.
+ */
+int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, size_t slot_stride,
+                       const uint32_t *d_len, size_t nblocks, void *hip_stream);
+
+/*
+ * Host-buffer batches: same per-block contract, buffers in host memory.  The call
+ * stages through device memory it allocates and frees itself and returns when the
+ * results are in `out` / `out_len`.  in_len_each may be NULL (every block in_len bytes).
+ */
+int lzs_compress_batch(uint8_t *out, size_t out_stride, size_t out_cap, uint32_t *out_len,
+                       const uint8_t *in, size_t in_stride, const uint32_t *in_len_each,
+                       size_t in_len, size_t nblocks);
+int lzs_decompress_batch(uint8_t *out, size_t out_stride, size_t out_cap, uint32_t *out_len,
+                         const uint8_t *in, size_t in_stride, const uint32_t *in_len_each,
+                         size_t in_len, size_t nblocks);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* LZS_MI355X_LZS_BATCH_H */

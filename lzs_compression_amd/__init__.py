@@ -1,0 +1,15 @@
+"""lzs_compression_amd -- MI355X-native LZS (RFC 1974/2395) block codec.
+
+The product is ``liblzs.so`` (C host + hand-written HIP kernels for gfx950) behind the
+reference's one-shot C-ABI (include/lzs/lzs.h); this package is its ctypes front-end plus
+the seeded workload generators used by the benchmark and tests.  No CPU codec, no
+fallback: without the built library or without a GPU, calls raise.
+"""
+from .api import (LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
+                  compressed_max, decompress, decompress_batch, decompress_blocks,
+                  decompressed_max, last_error, lib)
+from . import workload
+
+__all__ = ["LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
+           "compressed_max", "decompress", "decompress_batch", "decompress_blocks",
+           "decompressed_max", "last_error", "lib", "workload"]

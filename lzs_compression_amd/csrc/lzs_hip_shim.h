@@ -1,0 +1,45 @@
+/*
+ * lzs_hip_shim.h -- the thin extern-"C" seam between the C host library
+ * (lzs_host.c) and the HIP translation unit (lzs_kernels.hip).  Internal: not
+ * installed, not part of the public ABI (that is include/lzs/).
+ *
+ * Every function returns a hipError_t value as int (0 = hipSuccess) unless noted.
+ */
+#ifndef LZS_HIP_SHIM_H
+#define LZS_HIP_SHIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int         lzs_hip_device_count(int *count);
+int         lzs_hip_describe(char *buf, size_t cap);          /* "hip gfx950 ..., N CUs, ..." */
+const char *lzs_hip_strerror(int hip_error);
+
+int lzs_hip_malloc(void **p, size_t bytes);
+int lzs_hip_free(void *p);
+int lzs_hip_stream_create(void **stream);
+int lzs_hip_stream_destroy(void *stream);
+int lzs_hip_stream_sync(void *stream);
+int lzs_hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int lzs_hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int lzs_hip_memset(void *dst, int value, size_t bytes, void *stream);
+
+/* Kernel launches (asynchronous on `stream`). */
+int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                            const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                            uint32_t in_len, uint32_t nblocks, void *stream);
+int lzs_hip_launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                              const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                              uint32_t in_len, uint32_t nblocks, void *stream);
+int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
+                           size_t slot_stride, const uint32_t *d_len, uint32_t nblocks,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

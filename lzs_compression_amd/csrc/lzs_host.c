@@ -1,0 +1,229 @@
+/*
+ * lzs_host.c -- the C host side of liblzs (MI355X build): argument checking, error
+ * reporting, host<->device staging.  All codec work happens in lzs_kernels.hip, reached
+ * through the extern-"C" shim in lzs_hip_shim.h.  There is deliberately NO CPU codec
+ * here: without a HIP device every entry point fails loudly.
+ *
+ * Public surface: include/lzs/lzs.h (the reference's one-shot calls,
+ * c/src/liblzs/lzs.h:218,229) and include/lzs/lzs_batch.h (additive batch calls).
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "lzs/lzs.h"
+#include "lzs/lzs_batch.h"
+#include "lzs_hip_shim.h"
+
+static _Thread_local char tls_error[512];
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tls_error, sizeof(tls_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(int hip_error, const char *what)
+{
+    return fail(LZS_E_HIP, "%s: %s", what, lzs_hip_strerror(hip_error));
+}
+
+const char *lzs_last_error(void) { return tls_error; }
+
+static int require_device(void)
+{
+    int n = 0;
+    int e = lzs_hip_device_count(&n);
+    if (e != 0 || n <= 0)
+        return fail(LZS_E_NO_DEVICE, "no HIP device available (%s); liblzs has no CPU codec",
+                    e ? lzs_hip_strerror(e) : "device count is 0");
+    return LZS_OK;
+}
+
+int lzs_backend_info(char *buf, size_t cap)
+{
+    if (!buf || cap == 0) return fail(LZS_E_ARG, "lzs_backend_info: no buffer");
+    int rc = require_device();
+    if (rc != LZS_OK) { snprintf(buf, cap, "%s", tls_error); return rc; }
+    int e = lzs_hip_describe(buf, cap);
+    if (e) { snprintf(buf, cap, "%s", lzs_hip_strerror(e)); return hip_fail(e, "hipGetDeviceProperties"); }
+    return LZS_OK;
+}
+
+/* ------------------------------------------------------------------ device batches */
+typedef int (*launch_fn)(void *, size_t, uint32_t, uint32_t *, const void *, size_t,
+                         const uint32_t *, uint32_t, uint32_t, void *);
+
+static int check_batch(const char *who, const void *out_len, const void *in, size_t in_len,
+                       size_t nblocks)
+{
+    if (nblocks == 0) return LZS_OK;
+    if (!out_len) return fail(LZS_E_ARG, "%s: out_len is NULL", who);
+    if (!in && in_len) return fail(LZS_E_ARG, "%s: input is NULL", who);
+    if (in_len > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "%s: block of %zu bytes exceeds LZS_BLOCK_MAX", who, in_len);
+    if (nblocks > 0x7FFFFFFFu) return fail(LZS_E_ARG, "%s: too many blocks (%zu)", who, nblocks);
+    return LZS_OK;
+}
+
+static int device_batch(const char *who, launch_fn launch, void *d_out, size_t out_stride,
+                        size_t out_cap, uint32_t *d_out_len, const void *d_in, size_t in_stride,
+                        const uint32_t *d_in_len, size_t in_len, size_t nblocks, void *stream)
+{
+    int rc = check_batch(who, d_out_len, d_in, in_len, nblocks);
+    if (rc != LZS_OK || nblocks == 0) return rc;
+    if (!d_out && out_cap) return fail(LZS_E_ARG, "%s: output is NULL", who);
+    uint32_t cap32 = out_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)out_cap;
+    int e = launch(d_out, out_stride, cap32, d_out_len, d_in, in_stride, d_in_len,
+                   (uint32_t)in_len, (uint32_t)nblocks, stream);
+    return e ? hip_fail(e, who) : LZS_OK;
+}
+
+int lzs_compress_batch_device(void *d_out, size_t out_stride, size_t out_cap, uint32_t *d_out_len,
+                              const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                              size_t in_len, size_t nblocks, void *hip_stream)
+{
+    return device_batch("lzs_compress_batch_device", lzs_hip_launch_compress, d_out, out_stride,
+                        out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, hip_stream);
+}
+
+int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, uint32_t *d_out_len,
+                                const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                                size_t in_len, size_t nblocks, void *hip_stream)
+{
+    return device_batch("lzs_decompress_batch_device", lzs_hip_launch_decompress, d_out, out_stride,
+                        out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, hip_stream);
+}
+
+int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, size_t slot_stride,
+                       const uint32_t *d_len, size_t nblocks, void *hip_stream)
+{
+    if (!d_offsets) return fail(LZS_E_ARG, "lzs_compact_device: d_offsets is NULL");
+    if (nblocks && (!d_slots || !d_len || !d_dense))
+        return fail(LZS_E_ARG, "lzs_compact_device: NULL buffer");
+    if (nblocks > 0x7FFFFFFFu) return fail(LZS_E_ARG, "lzs_compact_device: too many blocks");
+    int e = lzs_hip_launch_compact(d_dense, d_offsets, d_slots, slot_stride, d_len,
+                                   (uint32_t)nblocks, hip_stream);
+    return e ? hip_fail(e, "lzs_compact_device") : LZS_OK;
+}
+
+/* -------------------------------------------------------------------- host batches */
+/* Stage host buffers through device memory owned by this call.  Blocks are packed on
+ * the device with 16-byte-aligned strides so the kernels take their aligned paths,
+ * whatever the caller's strides are. */
+static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t out_stride,
+                      size_t out_cap, uint32_t *out_len, const uint8_t *in, size_t in_stride,
+                      const uint32_t *in_len_each, size_t in_len, size_t nblocks)
+{
+    int rc = check_batch(who, out_len, in, in_len, nblocks);
+    if (rc != LZS_OK || nblocks == 0) return rc;
+    if (!out && out_cap) return fail(LZS_E_ARG, "%s: output is NULL", who);
+    if (in_len_each) {
+        in_len = 0;
+        for (size_t b = 0; b < nblocks; b++) {
+            if (in_len_each[b] > in_len) in_len = in_len_each[b];
+        }
+        if (in_len > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "%s: block exceeds LZS_BLOCK_MAX", who);
+    }
+    if ((rc = require_device()) != LZS_OK) return rc;
+
+    const uint32_t cap32 = out_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)out_cap;
+    const size_t d_in_stride = round_up(in_len ? in_len : 1, 16);
+    const size_t d_out_stride = round_up(cap32 ? cap32 : 1, 16);
+    void *stream = NULL, *d_in = NULL, *d_out = NULL, *d_len = NULL, *d_in_len = NULL;
+    int e = 0;
+    rc = LZS_OK;
+
+#define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto done; } } while (0)
+    HIP_TRY(lzs_hip_stream_create(&stream), "hipStreamCreate");
+    e = lzs_hip_malloc(&d_in, d_in_stride * nblocks);
+    if (!e) e = lzs_hip_malloc(&d_out, d_out_stride * nblocks);
+    if (!e) e = lzs_hip_malloc(&d_len, sizeof(uint32_t) * nblocks);
+    if (!e && in_len_each) e = lzs_hip_malloc(&d_in_len, sizeof(uint32_t) * nblocks);
+    if (e) { rc = fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
+
+    if (in_stride == d_in_stride && !in_len_each) {
+        HIP_TRY(lzs_hip_h2d(d_in, in, d_in_stride * (nblocks - 1) + in_len, stream), "hipMemcpy H2D");
+    } else {
+        for (size_t b = 0; b < nblocks; b++) {
+            size_t len_b = in_len_each ? in_len_each[b] : in_len;
+            HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + b * d_in_stride, in + b * in_stride, len_b, stream),
+                    "hipMemcpy H2D");
+        }
+    }
+    if (in_len_each)
+        HIP_TRY(lzs_hip_h2d(d_in_len, in_len_each, sizeof(uint32_t) * nblocks, stream), "hipMemcpy H2D");
+
+    HIP_TRY(launch(d_out, d_out_stride, cap32, (uint32_t *)d_len, d_in, d_in_stride,
+                   (const uint32_t *)d_in_len, (uint32_t)in_len, (uint32_t)nblocks, stream), who);
+    HIP_TRY(lzs_hip_d2h(out_len, d_len, sizeof(uint32_t) * nblocks, stream), "hipMemcpy D2H");
+    HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    /* copy back only what each block produced: nothing past out_len[b] is touched */
+    for (size_t b = 0; b < nblocks; b++)
+        HIP_TRY(lzs_hip_d2h(out + b * out_stride, (uint8_t *)d_out + b * d_out_stride, out_len[b], stream),
+                "hipMemcpy D2H");
+    HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+#undef HIP_TRY
+
+done:
+    if (d_in) lzs_hip_free(d_in);
+    if (d_out) lzs_hip_free(d_out);
+    if (d_len) lzs_hip_free(d_len);
+    if (d_in_len) lzs_hip_free(d_in_len);
+    if (stream) lzs_hip_stream_destroy(stream);
+    return rc;
+}
+
+int lzs_compress_batch(uint8_t *out, size_t out_stride, size_t out_cap, uint32_t *out_len,
+                       const uint8_t *in, size_t in_stride, const uint32_t *in_len_each,
+                       size_t in_len, size_t nblocks)
+{
+    return host_batch("lzs_compress_batch", lzs_hip_launch_compress, out, out_stride, out_cap,
+                      out_len, in, in_stride, in_len_each, in_len, nblocks);
+}
+
+int lzs_decompress_batch(uint8_t *out, size_t out_stride, size_t out_cap, uint32_t *out_len,
+                         const uint8_t *in, size_t in_stride, const uint32_t *in_len_each,
+                         size_t in_len, size_t nblocks)
+{
+    return host_batch("lzs_decompress_batch", lzs_hip_launch_decompress, out, out_stride, out_cap,
+                      out_len, in, in_stride, in_len_each, in_len, nblocks);
+}
+
+/* ---------------------------------------------- the reference's one-shot entry points */
+static size_t one_shot(const char *who, launch_fn launch, uint8_t *out, size_t cap,
+                       const uint8_t *in, size_t n)
+{
+    uint32_t got = 0;
+    tls_error[0] = 0;       /* so that a non-empty lzs_last_error() after a 0 return means failure */
+    /* The stream can never be longer than the worst case, so a huge caller buffer need not
+     * be mirrored on the device in full. */
+    size_t useful = cap;
+    if (launch == lzs_hip_launch_compress) {
+        size_t worst = LZS_COMPRESSED_MAX(n);
+        if (useful > worst) useful = worst;
+    } else {
+        size_t worst = n > (SIZE_MAX / 16u) ? SIZE_MAX : LZS_DECOMPRESSED_MAX(n);
+        if (useful > worst) useful = worst;
+    }
+    int rc = host_batch(who, launch, out, 0, useful, &got, in, 0, NULL, n, 1);
+    if (rc != LZS_OK) {
+        fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+        return 0;
+    }
+    return got;
+}
+
+size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
+{
+    return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+}
+
+size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
+{
+    return one_shot("lzs_decompress", lzs_hip_launch_decompress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+}

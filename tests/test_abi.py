@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+the public headers declare, keeps the reference's macros, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import lzs_compression_amd as lzs
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+INC = os.path.join(ROOT, "include")
+
+
+def _declared_functions():
+    names = []
+    for hdr in ("lzs/lzs.h", "lzs/lzs_batch.h"):
+        text = open(os.path.join(INC, hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(lzs_[a-z_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = lzs.lib()
+    declared = _declared_functions()
+    assert {"lzs_compress", "lzs_decompress", "lzs_compress_batch_device",
+            "lzs_decompress_batch_device", "lzs_compact_device", "lzs_compress_batch",
+            "lzs_decompress_batch", "lzs_backend_info", "lzs_last_error"} <= set(declared)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_headers_compile_as_c99_and_keep_reference_macros(tmp_path):
+    """A C99 caller of the reference's one-shot interface compiles unchanged against our
+    header; LZS_COMPRESSED_MAX/LZS_DECOMPRESSED_MAX keep their values (lzs.h:77,81)."""
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include "lzs.h"
+#include "lzs_batch.h"
+#include <stdio.h>
+int main(void) {
+    size_t (*c)(uint8_t *, size_t, const uint8_t *, size_t) = lzs_compress;
+    size_t (*d)(uint8_t *, size_t, const uint8_t *, size_t) = lzs_decompress;
+    printf("%u %u %u %u %u %d\n", (unsigned)LZS_COMPRESSED_MAX(65536u), (unsigned)LZS_COMPRESSED_MAX(4096u),
+           (unsigned)LZS_DECOMPRESSED_MAX(10u), (unsigned)LZS_MAX_HISTORY_SIZE,
+           (unsigned)LZS_MAX_LOOK_AHEAD_LEN, (c != 0) && (d != 0));
+    return 0;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{INC}/lzs", str(src),
+                    f"-L{ROOT}/lzs_compression_amd", "-llzs",
+                    f"-Wl,-rpath,{ROOT}/lzs_compression_amd", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["73731", "4611", "160", "2047", "15", "1"]
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lzs.LzsError) as e:
+        lzs.compress(b"hello hello hello")
+    assert "no HIP device" in str(e.value) and "no CPU codec" in str(e.value)
+    with pytest.raises(lzs.LzsError):
+        lzs.backend_info()
+    # the raw C call returns 0 bytes and leaves the buffer alone
+    lib = lzs.lib()
+    dst = ctypes.create_string_buffer(b"\xAA" * 32, 32)
+    src = ctypes.create_string_buffer(b"abcabcabc", 9)
+    assert lib.lzs_compress(ctypes.addressof(dst), 32, ctypes.addressof(src), 9) == 0
+    assert dst.raw == b"\xAA" * 32
+    assert lib.lzs_last_error()
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped package and its native sources never import, link or open oracle/."""
+    pkg = os.path.join(ROOT, "lzs_compression_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "liblzs_oracle" not in text \
+                    and "oracle/" not in text.replace("SURVEY", ""), os.path.join(dirpath, f)
+    so = os.path.join(pkg, "liblzs.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
