@@ -37,7 +37,10 @@ extern "C" {
  * plus the end marker (reference lzs.h:75-77). */
 #define LZS_COMPRESSED_MAX(X)       ((X) + ((X) + 7u) / 8u + 3u)
 
-/* Worst-case size of decompressed data for X compressed bytes (reference lzs.h:79-81). */
+/* Worst-case size of decompressed data for X compressed bytes, exactly as the
+ * reference states it (lzs.h:79-81).  Note that long runs beat it: each 4-bit
+ * extension nibble expands to 15 bytes (30x); size output buffers from the known
+ * original length where there is one. */
 #define LZS_DECOMPRESSED_MAX(X)     ((X) * 16u)
 
 /*

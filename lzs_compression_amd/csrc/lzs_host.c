@@ -207,7 +207,9 @@ static size_t one_shot(const char *who, launch_fn launch, uint8_t *out, size_t c
         size_t worst = LZS_COMPRESSED_MAX(n);
         if (useful > worst) useful = worst;
     } else {
-        size_t worst = n > (SIZE_MAX / 16u) ? SIZE_MAX : LZS_DECOMPRESSED_MAX(n);
+        /* every 4-bit extension nibble can yield 15 bytes, so the true bound is 30x
+         * (the reference's LZS_DECOMPRESSED_MAX, 16x, under-estimates runs) */
+        size_t worst = n > (SIZE_MAX / 32u) ? SIZE_MAX : n * 30u + 64u;
         if (useful > worst) useful = worst;
     }
     int rc = host_batch(who, launch, out, 0, useful, &got, in, 0, NULL, n, 1);

@@ -145,7 +145,8 @@ def run_blocks(codec: _Codec, blocks: np.ndarray, *, decompress: bool = False,
     flat[:nb * stride] = blocks.reshape(-1)
     if out_cap is None:
         out_cap = stride if decompress else compressed_max(stride)
-    out = np.zeros((nb, out_cap), dtype=np.uint8)
+    out = np.empty((nb, out_cap), dtype=np.uint8)
+    out.fill(0)                      # touch the pages now, not inside the timed threads
     out_len = np.zeros(nb, dtype=np.uint32)
     if in_len is not None:
         in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
