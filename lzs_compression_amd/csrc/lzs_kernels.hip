@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "lzs_hip_shim.h"
 
@@ -117,10 +118,10 @@ struct Sink {
     bool     aligned4;
 };
 
-__device__ __forceinline__ void sink_flush_full(Sink &s, WaveLds &L, uint32_t lane)
+__device__ __forceinline__ void sink_flush_full(Sink &s, uint32_t *stage, uint32_t lane)
 {
     __builtin_amdgcn_wave_barrier();
-    const uint32_t v = L.stage[lane];
+    const uint32_t v = stage[lane];
     const uint32_t at = s.flushed + 4 * lane;
     if (s.aligned4 && at + 4 <= s.cap) {
         *reinterpret_cast<uint32_t *>(s.dst + at) = v;
@@ -133,24 +134,45 @@ __device__ __forceinline__ void sink_flush_full(Sink &s, WaveLds &L, uint32_t la
     s.fill = 0;
 }
 
-__device__ __forceinline__ void sink_put(Sink &s, WaveLds &L, uint32_t lane, uint32_t value, uint32_t width)
+__device__ __forceinline__ void sink_put(Sink &s, uint32_t *stage, uint32_t lane, uint32_t value, uint32_t width)
 {
     s.acc = (s.acc << width) | value;
     s.nbits += width;
     if (s.nbits >= 32) {
         s.nbits -= 32;
         const uint32_t word = (uint32_t)(s.acc >> s.nbits);
-        if (lane == 0) L.stage[s.fill >> 2] = __builtin_bswap32(word);
+        if (lane == 0) stage[s.fill >> 2] = __builtin_bswap32(word);
         s.fill += 4;
-        if (s.fill == kStage) sink_flush_full(s, L, lane);
+        if (s.fill == kStage) sink_flush_full(s, stage, lane);
     }
 }
 
+// End marker 1 1 0000000, zero pad to a byte, drain (lzs-compression.c:449-466); the
+// returned length is cut at the capacity like every byte before it.
+__device__ __forceinline__ void sink_finish(Sink &s, uint32_t *stage, uint32_t lane, uint32_t *len_out)
+{
+    sink_put(s, stage, lane, 0x180u, 9);
+    if (s.nbits & 7u) sink_put(s, stage, lane, 0u, 8u - (s.nbits & 7u));
+    uint8_t *stage8 = reinterpret_cast<uint8_t *>(stage);
+    const uint32_t tail = s.nbits >> 3;                 // 0..3 whole bytes left in acc
+    if (lane < tail) stage8[s.fill + lane] = (uint8_t)(s.acc >> (s.nbits - 8 - 8 * lane));
+    s.fill += tail;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < s.fill; i += 64) {
+        const uint32_t at = s.flushed + i;
+        if (at < s.cap) s.dst[at] = stage8[i];
+    }
+    const uint32_t total = s.flushed + s.fill;
+    if (lane == 0) *len_out = total < s.cap ? total : s.cap;
+}
+
 // ---------------------------------------------------------------------------------
-// lzs_compress() per block.  reference lzs-compression.c:249-467
+// lzs_compress() per block, variant "scan": every token start scans all offsets, 64 per
+// round, nearest first.  Simple and data-independent; kept as the A/B baseline.
+// reference lzs-compression.c:249-467
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWavesPerWG * 64)
-void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
+void lzs_compress_blocks_scan_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
                                 uint32_t *__restrict__ out_len,
                                 const uint8_t *__restrict__ in, size_t in_stride,
                                 const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
@@ -218,17 +240,17 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
         const uint32_t len = best >> 11;
         if (len < 2) {
             // ---- literal: 0 bbbbbbbb (:365-375)
-            sink_put(s, L, lane, ring_byte(L.ring, c) & 0xFFu, 9);
+            sink_put(s, L.stage, lane, ring_byte(L.ring, c) & 0xFFu, 9);
             c += 1;
             continue;
         }
         // ---- match head: 1, offset, first length code (:376-409)
         const uint32_t off = kWindow - (best & kWindow);
         const uint32_t first = len < kTokenMax ? len : kTokenMax;
-        if (off <= kShortMax) sink_put(s, L, lane, (3u << 7) | off, 9);
-        else                  sink_put(s, L, lane, (2u << 11) | off, 13);
-        if (first <= 4) sink_put(s, L, lane, first - 2, 2);
-        else            sink_put(s, L, lane, 0xCu + (first - 5), 4);
+        if (off <= kShortMax) sink_put(s, L.stage, lane, (3u << 7) | off, 9);
+        else                  sink_put(s, L.stage, lane, (2u << 11) | off, 13);
+        if (first <= 4) sink_put(s, L.stage, lane, first - 2, 2);
+        else            sink_put(s, L.stage, lane, 0xCu + (first - 5), 4);
         c += first;
         if (first == kTokenMax) {
             // ---- extension nibbles at the same offset (:417-431)
@@ -247,28 +269,247 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
                                      ring_byte(L.ring, c + lane) != ring_byte(L.ring, c + lane - off);
                 const uint64_t stop = __ballot(differs) | (1ull << elim);
                 e = uniform((uint32_t)__builtin_ctzll(stop));
-                sink_put(s, L, lane, e, 4);
+                sink_put(s, L.stage, lane, e, 4);
                 c += e;
             } while (e == kNibbleMax);
         }
     }
 
-    // ---- end marker 1 1 0000000, zero pad to a byte (:449-466)
-    sink_put(s, L, lane, 0x180u, 9);
-    if (s.nbits & 7u) sink_put(s, L, lane, 0u, 8u - (s.nbits & 7u));
-    {
-        uint8_t *stage8 = reinterpret_cast<uint8_t *>(L.stage);
-        const uint32_t tail = s.nbits >> 3;                 // 0..3 whole bytes left in acc
-        if (lane < tail) stage8[s.fill + lane] = (uint8_t)(s.acc >> (s.nbits - 8 - 8 * lane));
-        s.fill += tail;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < s.fill; i += 64) {
-            const uint32_t at = s.flushed + i;
-            if (at < s.cap) s.dst[at] = stage8[i];
-        }
-        const uint32_t total = s.flushed + s.fill;
-        if (lane == 0) out_len[b] = total < s.cap ? total : s.cap;
+    sink_finish(s, L.stage, lane, &out_len[b]);
+}
+
+// ---------------------------------------------------------------------------------
+// lzs_compress() per block, variant "chain" (the default).
+//
+// The search rule is a pure function of (input, position), so it is hoisted out of the
+// serial parse and made position-parallel: the wave takes 64 consecutive positions at a
+// time (lane = position) and
+//   1. BUILD   inserts them into a previous-occurrence chain keyed by a hash of the two
+//              bytes at the position -- only offsets whose first two bytes match can give
+//              a match >= 2, so the chain is a complete candidate list (the reference's
+//              hash chains, lzs-compression.c:328-361,435-443, exploit the same fact);
+//   2. SEARCH  every lane walks its own chain nearest-first, comparing 12 bytes per
+//              candidate, keeping the first strictly longer match, stopping at the cap or
+//              when the chain leaves the 2047-byte window (lzs-compression.c:334-361);
+//   3. PARSE   the wave then runs the greedy token loop over those 64 results, reading
+//              each token's (length, offset) from the owning lane, and packs bits
+//              (lzs-compression.c:365-431).
+// Positions swallowed by a long match are built but not searched.
+//
+// Chain storage, per wave, in LDS:
+//   head[2048]  low 16 bits of the latest position per hash (stale/aliased entries only
+//               ever add byte-verified candidates at increasing distance: harmless);
+//   link[2112]  per position (ring of 33 batches): distance to the previous position
+//               with the same hash.
+// Several lanes of one batch may share a hash; their order is resolved exactly by an
+// in-wave bitonic sort of (hash, lane), not by relying on LDS write-conflict order.
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kHashBits  = 11;
+constexpr uint32_t kHeads     = 1u << kHashBits;
+constexpr uint32_t kLinkSlots = 2112;            // 33 x 64 >= 2047 + 64
+
+struct __attribute__((aligned(16))) ChainLds {
+    uint32_t ring[kRingWords + 4];               // +16 B mirror of ring[0..15]: reads never wrap
+    uint16_t head[kHeads];
+    uint16_t link[kLinkSlots];
+    uint32_t stage[kStage / 4];
+};
+
+__device__ __forceinline__ void ringm_read12(const uint32_t *ring, uint32_t q,
+                                             uint32_t &w0, uint32_t &w1, uint32_t &w2)
+{
+    const uint32_t a = (q & kRingMask) >> 2;     // words a..a+3 exist thanks to the mirror
+    const uint32_t s = q & 3;
+    const uint32_t d0 = ring[a], d1 = ring[a + 1], d2 = ring[a + 2], d3 = ring[a + 3];
+    w0 = __builtin_amdgcn_alignbyte(d1, d0, s);
+    w1 = __builtin_amdgcn_alignbyte(d2, d1, s);
+    w2 = __builtin_amdgcn_alignbyte(d3, d2, s);
+}
+
+__device__ __forceinline__ void chain_refill(ChainLds &L, const uint8_t *src, uint32_t n, bool src16,
+                                             uint32_t lane, uint32_t &loaded, uint32_t need)
+{
+    while (loaded < n && loaded < need) {
+        const uint32_t p = loaded + 16 * lane;
+        const uint4 v = load16(src, p, n, src16);
+        const uint32_t at = (p & kRingMask) >> 2;
+        *reinterpret_cast<uint4 *>(&L.ring[at]) = v;
+        if (at == 0) *reinterpret_cast<uint4 *>(&L.ring[kRingWords]) = v;
+        loaded += kTile;
     }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Ascending bitonic sort of one value per lane across the wave.
+__device__ __forceinline__ uint32_t wave_sort(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)v, (int)j, 64);
+            const bool up = (lane & k) == 0 || k == 64;
+            const bool low = (lane & j) == 0;
+            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (low == up) ? mn : mx;
+        }
+    }
+    return v;
+}
+
+// BUILD for the batch starting at position B (multiple of 64).  Returns this lane's 12
+// bytes (t0..t2) and its chain distance (0 = no previous position with this hash).
+__device__ __forceinline__ uint32_t chain_build(ChainLds &L, uint32_t B, uint32_t n, uint32_t lane,
+                                                uint32_t &t0, uint32_t &t1, uint32_t &t2)
+{
+    const uint32_t p = B + lane;
+    ringm_read12(L.ring, p, t0, t1, t2);
+    const bool has2 = p + 1 < n;                              // a 2-gram starts here
+    const uint32_t gram = t0 & 0xFFFFu;
+    const uint32_t h = has2 ? ((gram * 40503u) >> 5) & (kHeads - 1) : kHeads + lane;
+    // nearest lower lane with the same hash, and whether this lane is the last of its hash
+    const uint32_t sorted = wave_sort((h << 6) | lane, lane);
+    const uint32_t before = (uint32_t)__shfl_up((int)sorted, 1, 64);
+    const uint32_t after  = (uint32_t)__shfl_down((int)sorted, 1, 64);
+    const bool same = lane > 0 && (before >> 6) == (sorted >> 6);
+    const bool last = lane == 63 || (after >> 6) != (sorted >> 6);
+    const uint32_t note = (same ? (0x40u | (before & 63u)) : 0u) | (last ? 0x80u : 0u);
+    // hand the note back to the lane that owns the position
+    const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_permute((int)((sorted & 63u) << 2), (int)note);
+
+    const uint32_t old = has2 ? L.head[h] : 0u;
+    uint32_t dist;
+    if (mine & 0x40u) dist = lane - (mine & 63u);
+    else              dist = (p - old) & 0xFFFFu;
+    if (!has2) dist = 0;
+    const uint32_t slot = ((B >> 6) % 33u) * 64u + lane;
+    L.link[slot] = (uint16_t)dist;
+    __builtin_amdgcn_wave_barrier();
+    if (has2 && (mine & 0x80u)) L.head[h] = (uint16_t)p;
+    __builtin_amdgcn_wave_barrier();
+    return dist;
+}
+
+__global__ __launch_bounds__(kWavesPerWG * 64)
+void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
+                                uint32_t *__restrict__ out_len,
+                                const uint8_t *__restrict__ in, size_t in_stride,
+                                const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
+                                uint32_t nblocks)
+{
+    __shared__ ChainLds lds[kWavesPerWG];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv   = threadIdx.x >> 6;
+    const uint32_t b    = blockIdx.x * kWavesPerWG + wv;
+    if (b >= nblocks) return;
+
+    ChainLds &L = lds[wv];
+    const uint8_t *src = in + (size_t)b * in_stride;
+    const uint32_t n   = in_len ? in_len[b] : in_len_uniform;
+    const bool src16   = ((uintptr_t)src & 15u) == 0;
+
+    Sink s;
+    s.acc = 0; s.nbits = 0; s.fill = 0; s.flushed = 0;
+    s.dst = out + (size_t)b * out_stride;
+    s.cap = out_cap;
+    s.aligned4 = ((uintptr_t)s.dst & 3u) == 0;
+
+    // never-set heads must look far away: 0x8000 is > 2047 from every early position, and a
+    // later alias is only a byte-verified extra candidate
+    for (uint32_t i = lane; i < kHeads / 2; i += 64)
+        reinterpret_cast<uint32_t *>(L.head)[i] = 0x80008000u;
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t c = 0;          // start of the next token
+    uint32_t loaded = 0;     // ring holds [loaded-4096, loaded)
+    uint32_t next = 0;       // next batch to build (multiple of 64)
+
+    while (c < n) {
+        if (s.flushed >= s.cap) break;                        // output full (:306-309)
+        const uint32_t B = next;
+        chain_refill(L, src, n, src16, lane, loaded, (B > c ? B : c) + 80);
+        uint32_t t0, t1, t2;
+        uint32_t dist = chain_build(L, B, n, lane, t0, t1, t2);
+        next = B + 64;
+        if (c >= next) continue;                              // batch lies inside a match
+
+        // ---- SEARCH (lane = position): lzs-compression.c:322-363
+        const uint32_t p = B + lane;
+        const uint32_t lim = p < n ? (n - p < kSearchCap ? n - p : kSearchCap) : 0u;
+        const uint32_t reach = p < kWindow ? p : kWindow;
+        const uint32_t myslot = ((B >> 6) % 33u) * 64u + lane;
+        bool walking = p >= c && lim >= 2;
+        uint32_t best_len = 0, best_off = 0, cum = 0;
+        for (;;) {
+            cum += dist;
+            walking = walking && dist != 0 && cum <= reach;
+            if (!__any(walking)) break;
+            if (walking) {
+                uint32_t w0, w1, w2;
+                ringm_read12(L.ring, p - cum, w0, w1, w2);
+                const uint32_t e0 = eq_bytes(w0 ^ t0);
+                const uint32_t e1 = eq_bytes(w1 ^ t1);
+                const uint32_t e2 = eq_bytes(w2 ^ t2);
+                uint32_t len = e0 + (e0 == 4 ? e1 + (e1 == 4 ? e2 : 0u) : 0u);
+                len = len < lim ? len : lim;
+                if (len > best_len) { best_len = len; best_off = cum; }   // strict: nearest wins
+                if (len == lim) walking = false;                          // :341-344
+                int32_t at = (int32_t)myslot - (int32_t)cum;
+                if (at < 0) at += (int32_t)kLinkSlots;
+                dist = L.link[at];
+            }
+        }
+        const uint32_t found = (best_len << 11) | best_off;
+
+        // ---- PARSE + PACK the tokens that start in this batch
+        const uint32_t stop = next < n ? next : n;
+        while (c < stop) {
+            if (s.flushed >= s.cap) break;
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)found, (int)uniform(c - B));
+            const uint32_t len = r >> 11;
+            if (len < 2) {                                    // literal (:365-375)
+                const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)uniform(c - B)) & 0xFFu;
+                sink_put(s, L.stage, lane, lit, 9);
+                c += 1;
+                continue;
+            }
+            const uint32_t off = r & kWindow;                 // match head (:376-409)
+            const uint32_t first = len < kTokenMax ? len : kTokenMax;
+            if (off <= kShortMax) sink_put(s, L.stage, lane, (3u << 7) | off, 9);
+            else                  sink_put(s, L.stage, lane, (2u << 11) | off, 13);
+            if (first <= 4) sink_put(s, L.stage, lane, first - 2, 2);
+            else            sink_put(s, L.stage, lane, 0xCu + (first - 5), 4);
+            c += first;
+            if (first == kTokenMax) {
+                // extension at the same offset (:417-431), up to 60 bytes = 4 nibbles per round
+                bool more = true;
+                while (more) {
+                    chain_refill(L, src, n, src16, lane, loaded, c + 64);
+                    // keep the chains current while c runs ahead: build every batch that is
+                    // now wholly behind c (its bytes must still be in the ring)
+                    while (next + 128 <= c) {
+                        uint32_t u0, u1, u2;
+                        chain_build(L, next, n, lane, u0, u1, u2);
+                        next += 64;
+                    }
+                    const uint32_t rem = n - c;
+                    const uint32_t span = rem < 60u ? rem : 60u;
+                    const bool differs = lane < span &&
+                                         ring_byte(L.ring, c + lane) != ring_byte(L.ring, c + lane - off);
+                    const uint64_t stopmask = __ballot(differs) | (1ull << span);
+                    const uint32_t m = uniform((uint32_t)__builtin_ctzll(stopmask));  // equal bytes <= span
+                    c += m;
+                    for (uint32_t k = m / kNibbleMax; k > 0; k--) sink_put(s, L.stage, lane, kNibbleMax, 4);
+                    // 60 equal bytes = four full nibbles and the match may go on; anything
+                    // shorter ends it with a last nibble of 0..14 (0 when it ended on a
+                    // multiple of 15 or at the end of the input)
+                    more = (m == 60u);
+                    if (!more) sink_put(s, L.stage, lane, m % kNibbleMax, 4);
+                }
+            }
+        }
+    }
+    sink_finish(s, L.stage, lane, &out_len[b]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -519,9 +760,19 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
 {
     if (nblocks == 0) return 0;
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
-                       (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+    // LZS_KERNEL=scan selects the brute-force variant (A/B and cross-checking); default "chain"
+    static const bool use_scan = [] {
+        const char *v = getenv("LZS_KERNEL");
+        return v && v[0] == 's';
+    }();
+    if (use_scan)
+        hipLaunchKernelGGL(lzs_compress_blocks_scan_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+    else
+        hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
     return (int)hipGetLastError();
 }
 
