@@ -180,7 +180,7 @@ void lzs_compress_blocks_scan_kernel(uint8_t *__restrict__ out, size_t out_strid
 {
     __shared__ WaveLds lds[kWavesPerWG];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv   = threadIdx.x >> 6;
+    const uint32_t wv   = uniform(threadIdx.x >> 6);   // wave-uniform, and the compiler knows it
     const uint32_t b    = blockIdx.x * kWavesPerWG + wv;
     if (b >= nblocks) return;
 
@@ -279,40 +279,189 @@ void lzs_compress_blocks_scan_kernel(uint8_t *__restrict__ out, size_t out_strid
 }
 
 // ---------------------------------------------------------------------------------
+// Lane-parallel output: a 4096-bit ring of big-endian words in LDS.  Tokens are OR-ed in
+// at their bit offsets (many lanes at once, offsets from a wave prefix sum of the token
+// widths), and each 2048-bit half is drained to HBM with one coalesced store as soon as it
+// is complete.  State is wave-uniform.  Truncation as lzs-compression.c:304-313.
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kBitWords = 128;                  // 512 B
+
+struct BitRing {
+    uint32_t flushed;    // bytes handed to HBM (multiple of 256)
+    uint32_t head;       // bits appended past `flushed` (< 4096)
+    uint8_t *dst;
+    uint32_t cap;
+    bool     aligned4;
+};
+
+__device__ __forceinline__ uint32_t br_at(const BitRing &e) { return ((e.flushed << 3) + e.head) & 4095u; }
+
+// OR the low `width` (1..32) bits of `value`, MSB first, at ring bit offset `at`.
+__device__ __forceinline__ void br_or(uint32_t *words, uint32_t at, uint32_t value, uint32_t width)
+{
+    const uint32_t sh = at & 31u, d = at >> 5;
+    const uint64_t v = (uint64_t)value << (64u - sh - width);
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    __hip_atomic_fetch_or(&words[d], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lo) __hip_atomic_fetch_or(&words[(d + 1) & (kBitWords - 1)], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void br_flush(BitRing &e, uint32_t *words, uint32_t lane)
+{
+    while (e.head >= 2048u) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t slot = ((e.flushed >> 8) & 1u) * 64u + lane;
+        const uint32_t v = __builtin_bswap32(words[slot]);
+        words[slot] = 0;
+        const uint32_t at = e.flushed + 4 * lane;
+        if (e.aligned4 && at + 4 <= e.cap) {
+            *reinterpret_cast<uint32_t *>(e.dst + at) = v;
+        } else {
+            for (uint32_t k = 0; k < 4; k++)
+                if (at + k < e.cap) e.dst[at + k] = (uint8_t)(v >> (8 * k));
+        }
+        __builtin_amdgcn_wave_barrier();
+        e.flushed += 256u;
+        e.head -= 2048u;
+    }
+}
+
+// one field from the whole wave (wave-uniform value/width)
+__device__ __forceinline__ void br_put(BitRing &e, uint32_t *words, uint32_t lane, uint32_t value, uint32_t width)
+{
+    if (lane == 0) br_or(words, br_at(e), value, width);
+    e.head += width;
+    br_flush(e, words, lane);
+}
+
+// Inclusive prefix sum across the wave with DPP adds only (no LDS round trips):
+// row_shr 1/2/4/8 scan each row of 16, row_bcast 15/31 carry the row totals upward.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// Emit the tokens that start at the marked lanes of one 64-position chunk (lane = position);
+// `r` is the lane's search result (len << 11 | off, len < 8 here), `byte` its input byte.
+// Token formats: lzs-compression.c:365-409.
+__device__ __forceinline__ void br_emit_chunk(BitRing &e, uint32_t *words, uint32_t lane,
+                                              uint64_t marks, uint32_t r, uint32_t byte)
+{
+    if (marks == 0ull) return;
+    const bool mine = (marks >> lane) & 1ull;
+    const uint32_t len = r >> 11, off = r & kWindow;
+    uint32_t value = byte & 0xFFu, width = 9;                         // 0 bbbbbbbb
+    if (len >= 2) {
+        const uint32_t ov = off <= kShortMax ? ((3u << 7) | off) : ((2u << 11) | off);
+        const uint32_t ow = off <= kShortMax ? 9u : 13u;
+        const uint32_t lv = len <= 4 ? len - 2 : 0xCu + (len - 5);
+        const uint32_t lw = len <= 4 ? 2u : 4u;
+        value = (ov << lw) | lv;
+        width = ow + lw;
+    }
+    const uint32_t w = mine ? width : 0u;
+    const uint32_t incl = wave_inclusive_sum(w);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (mine) br_or(words, (br_at(e) + incl - w) & 4095u, value, width);
+    e.head += total;
+    br_flush(e, words, lane);
+}
+
+// End marker 1 1 0000000, zero pad to a byte, drain (lzs-compression.c:449-466).
+__device__ __forceinline__ void br_finish(BitRing &e, uint32_t *words, uint32_t lane, uint32_t *len_out)
+{
+    br_put(e, words, lane, 0x180u, 9);
+    e.head = (e.head + 7u) & ~7u;                                     // pad bits are already zero
+    br_flush(e, words, lane);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nbytes = e.head >> 3;
+    for (uint32_t i = lane; i < nbytes; i += 64) {
+        const uint32_t bit = ((e.flushed << 3) + 8 * i) & 4095u;
+        const uint32_t v = (words[bit >> 5] >> (24u - (bit & 24u))) & 0xFFu;
+        if (e.flushed + i < e.cap) e.dst[e.flushed + i] = (uint8_t)v;
+    }
+    const uint32_t total = e.flushed + nbytes;
+    if (lane == 0) *len_out = total < e.cap ? total : e.cap;
+}
+
+// ---------------------------------------------------------------------------------
 // lzs_compress() per block, variant "chain" (the default).
 //
 // The search rule is a pure function of (input, position), so it is hoisted out of the
-// serial parse and made position-parallel: the wave takes 64 consecutive positions at a
-// time (lane = position) and
-//   1. BUILD   inserts them into a previous-occurrence chain keyed by a hash of the two
-//              bytes at the position -- only offsets whose first two bytes match can give
-//              a match >= 2, so the chain is a complete candidate list (the reference's
-//              hash chains, lzs-compression.c:328-361,435-443, exploit the same fact);
-//   2. SEARCH  every lane walks its own chain nearest-first, comparing 12 bytes per
-//              candidate, keeping the first strictly longer match, stopping at the cap or
-//              when the chain leaves the 2047-byte window (lzs-compression.c:334-361);
-//   3. PARSE   the wave then runs the greedy token loop over those 64 results, reading
-//              each token's (length, offset) from the owning lane, and packs bits
-//              (lzs-compression.c:365-431).
+// serial parse and made position-parallel.  One wave owns one block and works in rounds
+// over a POOL of 512 consecutive positions:
+//   1. BUILD   insert the pool's positions, 64 per instruction, into two
+//              previous-occurrence chains: one keyed by a hash of the 3 bytes at the
+//              position, one by a hash of 2.  Only offsets whose first bytes match can
+//              give a match, so each chain is a complete, nearest-first candidate list for
+//              its length class (the reference's chains, lzs-compression.c:328-361,435-443,
+//              rest on the same fact with a 2-byte key).
+//   2. SEARCH  lanes pull positions from the pool as they become free (walk lengths vary
+//              a lot, so lane = position would idle most lanes).  A position first walks
+//              its 3-byte chain through the whole window: every offset with a common
+//              prefix >= 3 is on it, so the nearest-longest rule (:337-345) is decided
+//              there whenever any match >= 3 exists.  Otherwise the answer is the nearest
+//              true 2-byte match: the first verified candidate on the 2-byte chain.
+//   3. PARSE   the greedy token loop (:365-431) runs on the scalar unit over the pool's
+//              results and packs bits.
 // Positions swallowed by a long match are built but not searched.
 //
-// Chain storage, per wave, in LDS:
-//   head[2048]  low 16 bits of the latest position per hash (stale/aliased entries only
-//               ever add byte-verified candidates at increasing distance: harmless);
-//   link[2112]  per position (ring of 33 batches): distance to the previous position
-//               with the same hash.
-// Several lanes of one batch may share a hash; their order is resolved exactly by an
-// in-wave bitonic sort of (hash, lane), not by relying on LDS write-conflict order.
+// Chain storage, per wave, in LDS: head3[2048], head2[512] (latest position per hash),
+// link3[2560], link2[2560] (per position, ring of 40 batches: distance to the previous
+// position with the same hash; anything > 2047 means none).
+// Lanes of one build instruction that share a hash are chained by ONE ds_wrxchg_rtn: on
+// gfx950 same-address LDS atomics of one wave instruction apply in ascending lane order,
+// so each lane receives its nearest lower neighbour (or the older head).  That ordering
+// is a measured property, not an ISA promise: tools/probes/lds_order_probe.hip and
+// tests/test_gpu_lds_order.py check it on the device over 2.6e5 conflict patterns.
 // ---------------------------------------------------------------------------------
-constexpr uint32_t kHashBits  = 11;
-constexpr uint32_t kHeads     = 1u << kHashBits;
-constexpr uint32_t kLinkSlots = 2112;            // 33 x 64 >= 2047 + 64
+#ifdef LZS_PROFILE
+// Diagnostic build only (tools/probes/prof_compress): per-phase cycle sums over all waves.
+__device__ unsigned long long lzs_prof[16];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}
+#define PROF_MARK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; } while (0)
+#define PROF_COUNT(i, v) do { prof_acc[i] += (v); } while (0)
+#define PROF_T0 unsigned long long prof_u = __builtin_readcyclecounter()
+#define PROF_T1(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_u; } while (0)
+#define PROF_T0B unsigned long long prof_v = __builtin_readcyclecounter()
+#define PROF_T1B(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_v; } while (0)
+#define PROF_T0C unsigned long long prof_w = __builtin_readcyclecounter()
+#define PROF_T1C(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_w; } while (0)
+#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_COUNT(i, v)
+#define PROF_T0
+#define PROF_T1(i)
+#define PROF_T0B
+#define PROF_T1B(i)
+#define PROF_T0C
+#define PROF_T1C(i)
+#define PROF_DONE
+#endif
+
+constexpr uint32_t kPool      = 512;             // positions hoisted per round
+constexpr uint32_t kLinkN     = 2560;            // 40 x 64 >= 2047 + kPool
+constexpr uint32_t kHead3     = 2048;
+constexpr uint32_t kHead2     = 512;
+constexpr uint32_t kNoLink    = 0xFFFFu;
+constexpr uint32_t kRefillMin = 16;              // idle lanes that justify a refill pass
 
 struct __attribute__((aligned(16))) ChainLds {
     uint32_t ring[kRingWords + 4];               // +16 B mirror of ring[0..15]: reads never wrap
-    uint16_t head[kHeads];
-    uint16_t link[kLinkSlots];
-    uint32_t stage[kStage / 4];
+    uint32_t head3[kHead3];
+    uint32_t head2[kHead2];
+    uint16_t link3[kLinkN];
+    uint16_t link2[kLinkN];
+    uint16_t res[kPool];                         // (len << 11) | off per pool position
+    uint32_t bits[kBitWords];                    // output bit ring
 };
 
 __device__ __forceinline__ void ringm_read12(const uint32_t *ring, uint32_t q,
@@ -340,156 +489,216 @@ __device__ __forceinline__ void chain_refill(ChainLds &L, const uint8_t *src, ui
     __builtin_amdgcn_wave_barrier();
 }
 
-// Ascending bitonic sort of one value per lane across the wave.
-__device__ __forceinline__ uint32_t wave_sort(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)v, (int)j, 64);
-            const bool up = (lane & k) == 0 || k == 64;
-            const bool low = (lane & j) == 0;
-            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
-            v = (low == up) ? mn : mx;
-        }
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t link_slot_base(uint32_t B) { return ((B >> 6) % 40u) * 64u; }
 
-// BUILD for the batch starting at position B (multiple of 64).  Returns this lane's 12
-// bytes (t0..t2) and its chain distance (0 = no previous position with this hash).
-__device__ __forceinline__ uint32_t chain_build(ChainLds &L, uint32_t B, uint32_t n, uint32_t lane,
-                                                uint32_t &t0, uint32_t &t1, uint32_t &t2)
+// BUILD for the 64 positions starting at B (multiple of 64).
+__device__ __forceinline__ void chain_build(ChainLds &L, uint32_t B, uint32_t n, uint32_t lane)
 {
     const uint32_t p = B + lane;
-    ringm_read12(L.ring, p, t0, t1, t2);
-    const bool has2 = p + 1 < n;                              // a 2-gram starts here
-    const uint32_t gram = t0 & 0xFFFFu;
-    const uint32_t h = has2 ? ((gram * 40503u) >> 5) & (kHeads - 1) : kHeads + lane;
-    // nearest lower lane with the same hash, and whether this lane is the last of its hash
-    const uint32_t sorted = wave_sort((h << 6) | lane, lane);
-    const uint32_t before = (uint32_t)__shfl_up((int)sorted, 1, 64);
-    const uint32_t after  = (uint32_t)__shfl_down((int)sorted, 1, 64);
-    const bool same = lane > 0 && (before >> 6) == (sorted >> 6);
-    const bool last = lane == 63 || (after >> 6) != (sorted >> 6);
-    const uint32_t note = (same ? (0x40u | (before & 63u)) : 0u) | (last ? 0x80u : 0u);
-    // hand the note back to the lane that owns the position
-    const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_permute((int)((sorted & 63u) << 2), (int)note);
-
-    const uint32_t old = has2 ? L.head[h] : 0u;
-    uint32_t dist;
-    if (mine & 0x40u) dist = lane - (mine & 63u);
-    else              dist = (p - old) & 0xFFFFu;
-    if (!has2) dist = 0;
-    const uint32_t slot = ((B >> 6) % 33u) * 64u + lane;
-    L.link[slot] = (uint16_t)dist;
+    const uint32_t a = (p & kRingMask) >> 2;
+    const uint32_t t0 = __builtin_amdgcn_alignbyte(L.ring[a + 1], L.ring[a], p & 3);
+    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 21;           // 11 bits
+    const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 7) & (kHead2 - 1);  // 9 bits
+    uint32_t d3 = kNoLink, d2 = kNoLink;
+    // ds_wrxchg_rtn_b32: lanes sharing a slot are served in ascending lane order (see above)
+    if (p + 2 < n) {
+        const uint32_t old = __hip_atomic_exchange(&L.head3[h3], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t d = p - old;                       // old == ~0u (never set) -> p + 1: too far
+        d3 = d < kNoLink ? d : kNoLink;
+    }
+    if (p + 1 < n) {
+        const uint32_t old = __hip_atomic_exchange(&L.head2[h2], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t d = p - old;
+        d2 = d < kNoLink ? d : kNoLink;
+    }
+    const uint32_t slot = link_slot_base(B) + lane;
+    L.link3[slot] = (uint16_t)d3;
+    L.link2[slot] = (uint16_t)d2;
     __builtin_amdgcn_wave_barrier();
-    if (has2 && (mine & 0x80u)) L.head[h] = (uint16_t)p;
-    __builtin_amdgcn_wave_barrier();
-    return dist;
 }
 
-__global__ __launch_bounds__(kWavesPerWG * 64)
+__global__ __launch_bounds__(64)
 void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
                                 uint32_t *__restrict__ out_len,
                                 const uint8_t *__restrict__ in, size_t in_stride,
                                 const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
                                 uint32_t nblocks)
 {
-    __shared__ ChainLds lds[kWavesPerWG];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv   = threadIdx.x >> 6;
-    const uint32_t b    = blockIdx.x * kWavesPerWG + wv;
+    __shared__ ChainLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b    = blockIdx.x;
     if (b >= nblocks) return;
 
-    ChainLds &L = lds[wv];
     const uint8_t *src = in + (size_t)b * in_stride;
     const uint32_t n   = in_len ? in_len[b] : in_len_uniform;
     const bool src16   = ((uintptr_t)src & 15u) == 0;
 
-    Sink s;
-    s.acc = 0; s.nbits = 0; s.fill = 0; s.flushed = 0;
+    BitRing s;
+    s.flushed = 0; s.head = 0;
     s.dst = out + (size_t)b * out_stride;
     s.cap = out_cap;
     s.aligned4 = ((uintptr_t)s.dst & 3u) == 0;
 
-    // never-set heads must look far away: 0x8000 is > 2047 from every early position, and a
-    // later alias is only a byte-verified extra candidate
-    for (uint32_t i = lane; i < kHeads / 2; i += 64)
-        reinterpret_cast<uint32_t *>(L.head)[i] = 0x80008000u;
+    L.bits[lane] = 0; L.bits[64 + lane] = 0;
+    for (uint32_t i = lane; i < kHead3; i += 64) L.head3[i] = ~0u;
+    for (uint32_t i = lane; i < kHead2; i += 64) L.head2[i] = ~0u;
     __builtin_amdgcn_wave_barrier();
 
     uint32_t c = 0;          // start of the next token
     uint32_t loaded = 0;     // ring holds [loaded-4096, loaded)
-    uint32_t next = 0;       // next batch to build (multiple of 64)
+    uint32_t next = 0;       // next batch of 64 positions to build
+    PROF_DECL;
 
     while (c < n) {
         if (s.flushed >= s.cap) break;                        // output full (:306-309)
-        const uint32_t B = next;
-        chain_refill(L, src, n, src16, lane, loaded, (B > c ? B : c) + 80);
-        uint32_t t0, t1, t2;
-        uint32_t dist = chain_build(L, B, n, lane, t0, t1, t2);
-        next = B + 64;
-        if (c >= next) continue;                              // batch lies inside a match
+        PROF_MARK(4);
+        // batches wholly behind c (inside a match): keep the chains complete, no search
+        while (next + 64 <= c) {
+            chain_refill(L, src, n, src16, lane, loaded, c + 80);
+            chain_build(L, next, n, lane);
+            next += 64;
+        }
+        // ---- BUILD the pool [Pb, Pe)
+        const uint32_t Pb = next;
+        const uint32_t Pe = Pb + kPool < ((n + 63u) & ~63u) ? Pb + kPool : ((n + 63u) & ~63u);
+        chain_refill(L, src, n, src16, lane, loaded, (Pe > c ? Pe : c) + 80);
+        PROF_MARK(0);
+        for (uint32_t B = Pb; B < Pe; B += 64) chain_build(L, B, n, lane);
+        PROF_MARK(1);
+        next = Pe;
+        const uint32_t pend = Pe < n ? Pe : n;
+        const uint32_t slot0 = link_slot_base(Pb);
 
-        // ---- SEARCH (lane = position): lzs-compression.c:322-363
-        const uint32_t p = B + lane;
-        const uint32_t lim = p < n ? (n - p < kSearchCap ? n - p : kSearchCap) : 0u;
-        const uint32_t reach = p < kWindow ? p : kWindow;
-        const uint32_t myslot = ((B >> 6) % 33u) * 64u + lane;
-        bool walking = p >= c && lim >= 2;
-        uint32_t best_len = 0, best_off = 0, cum = 0;
-        for (;;) {
-            cum += dist;
-            walking = walking && dist != 0 && cum <= reach;
-            if (!__any(walking)) break;
-            if (walking) {
+        // ---- SEARCH with lanes pulling positions from the pool (:322-363).
+        // The loop body is written branch-free (selects, unconditional in-range LDS reads):
+        // one wave alone on its SIMD pays for every instruction, scalar mask juggling included.
+        {
+            uint32_t nextp = c > Pb ? c : Pb;
+            bool busy = false, three = false;
+            uint32_t p = Pb, t0 = 0, t1 = 0, t2 = 0, lim = 0, reach = 0, myslot = slot0, first2 = kNoLink;
+            uint32_t cum = 0, dist = kNoLink, best_len = 0, best_off = 0;
+            for (;;) {
+                const uint64_t idle = __ballot(!busy);
+                const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
+                if (nextp < pend && (nidle >= kRefillMin || nidle == 64u)) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    const uint32_t np = nextp + rank;
+                    const bool take = !busy && np < pend;
+                    const uint32_t pp = take ? np : p;                  // every lane reads in range
+                    uint32_t n0, n1, n2;
+                    ringm_read12(L.ring, pp, n0, n1, n2);
+                    uint32_t sl = slot0 + (pp - Pb);
+                    sl = sl >= kLinkN ? sl - kLinkN : sl;
+                    const uint32_t l3 = L.link3[sl], l2 = L.link2[sl];
+                    const uint32_t nlim = n - pp < kSearchCap ? n - pp : kSearchCap;
+                    p = pp; myslot = sl;
+                    t0 = take ? n0 : t0; t1 = take ? n1 : t1; t2 = take ? n2 : t2;
+                    lim = take ? nlim : lim;
+                    reach = take ? (pp < kWindow ? pp : kWindow) : reach;
+                    three = take ? nlim >= 3 : three;
+                    first2 = take ? (nlim >= 2 ? l2 : kNoLink) : first2;
+                    dist = take ? (nlim >= 3 ? l3 : (nlim >= 2 ? l2 : kNoLink)) : dist;
+                    cum = take ? 0u : cum;
+                    best_len = take ? 0u : best_len;
+                    best_off = take ? 0u : best_off;
+                    busy = busy || take;
+                    nextp += nidle;
+                }
+                if (__ballot(busy) == 0ull) break;
+                PROF_COUNT(5, 1);
+                PROF_COUNT(6, __builtin_popcountll(__ballot(busy)));
+
+                const uint32_t cum2 = cum + dist;
+                const bool inwin = busy && cum2 <= reach;
                 uint32_t w0, w1, w2;
-                ringm_read12(L.ring, p - cum, w0, w1, w2);
+                ringm_read12(L.ring, p - (inwin ? cum2 : 0u), w0, w1, w2);
+                int32_t at = (int32_t)myslot - (int32_t)(inwin ? cum2 : 0u);
+                at = at < 0 ? at + (int32_t)kLinkN : at;
+                const uint32_t nd = three ? L.link3[at] : L.link2[at];
                 const uint32_t e0 = eq_bytes(w0 ^ t0);
                 const uint32_t e1 = eq_bytes(w1 ^ t1);
                 const uint32_t e2 = eq_bytes(w2 ^ t2);
                 uint32_t len = e0 + (e0 == 4 ? e1 + (e1 == 4 ? e2 : 0u) : 0u);
                 len = len < lim ? len : lim;
-                if (len > best_len) { best_len = len; best_off = cum; }   // strict: nearest wins
-                if (len == lim) walking = false;                          // :341-344
-                int32_t at = (int32_t)myslot - (int32_t)cum;
-                if (at < 0) at += (int32_t)kLinkSlots;
-                dist = L.link[at];
+                // 3-byte chain: first strictly longer match wins, the cap ends the walk (:337-345);
+                // 2-byte chain: the first verified candidate is the answer
+                const bool better = three ? len > best_len : len >= 2;
+                const bool takeit = inwin && better;
+                best_len = takeit ? len : best_len;
+                best_off = takeit ? cum2 : best_off;
+                const bool ended = !inwin || (three ? len == lim : len >= 2);
+                // nothing >= 3 in the whole window: restart on the 2-byte chain
+                const bool fallback = busy && ended && three && best_len < 3;
+                const bool finish = busy && ended && !fallback;
+                cum = fallback ? 0u : cum2;
+                dist = fallback ? first2 : nd;
+                best_len = fallback ? 0u : best_len;
+                best_off = fallback ? 0u : best_off;
+                three = three && !fallback;
+                if (finish) L.res[p - Pb] = (uint16_t)((best_len << 11) | best_off);
+                busy = busy && !finish;
             }
         }
-        const uint32_t found = (best_len << 11) | best_off;
+        __builtin_amdgcn_wave_barrier();
+        PROF_MARK(2);
 
-        // ---- PARSE + PACK the tokens that start in this batch
-        const uint32_t stop = next < n ? next : n;
-        while (c < stop) {
+        // ---- PARSE + PACK, 64 positions (one chunk) at a time.  The greedy chase over token
+        // starts is scalar and touches one register per token; the tokens it marks are
+        // encoded and written by all lanes at once.  Only matches that reach the extended
+        // length field (first code 8) are handled one by one.
+        for (uint32_t k = (c - Pb) >> 6; Pb + 64 * k < pend; k++) {
+            const uint32_t base = Pb + 64 * k;
+            const uint32_t cend = base + 64 < pend ? base + 64 : pend;
+            if (c >= cend) continue;
             if (s.flushed >= s.cap) break;
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)found, (int)uniform(c - B));
-            const uint32_t len = r >> 11;
-            if (len < 2) {                                    // literal (:365-375)
-                const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)uniform(c - B)) & 0xFFu;
-                sink_put(s, L.stage, lane, lit, 9);
-                c += 1;
-                continue;
-            }
-            const uint32_t off = r & kWindow;                 // match head (:376-409)
-            const uint32_t first = len < kTokenMax ? len : kTokenMax;
-            if (off <= kShortMax) sink_put(s, L.stage, lane, (3u << 7) | off, 9);
-            else                  sink_put(s, L.stage, lane, (2u << 11) | off, 13);
-            if (first <= 4) sink_put(s, L.stage, lane, first - 2, 2);
-            else            sink_put(s, L.stage, lane, 0xCu + (first - 5), 4);
-            c += first;
-            if (first == kTokenMax) {
-                // extension at the same offset (:417-431), up to 60 bytes = 4 nibbles per round
+            PROF_T0;
+            const uint32_t r = L.res[64 * k + lane];
+            const uint32_t byte = ring_byte(L.ring, base + lane);
+            const uint32_t len_l = r >> 11;
+            // The chase runs on the scalar unit over bit planes of the per-position step
+            // (bytes a token starting there consumes, 1..8), so it needs no per-token lane read.
+            const uint32_t nvalid = cend - base;              // lanes past the pool end hold stale results
+            const uint64_t vmask = nvalid >= 64u ? ~0ull : ((1ull << nvalid) - 1ull);
+            const uint32_t sm1 = len_l < 2 ? 0u : (len_l < kTokenMax ? len_l - 1 : kTokenMax - 1);
+            const uint64_t matches = __ballot(len_l >= 2) & vmask;
+            const uint64_t isext = __ballot(len_l >= kTokenMax) & vmask;
+            const uint64_t s0 = __ballot(sm1 & 1u), s1 = __ballot(sm1 & 2u), s2 = __ballot(sm1 & 4u);
+            uint64_t marks = 0;
+            PROF_T1(9);
+            PROF_T0B;
+            while (c < cend) {
+                const uint32_t li = c - base;
+                const uint64_t ahead = matches >> li;
+                if ((ahead & 1ull) == 0ull) {                 // a run of literals: mark it whole
+                    const uint32_t left = cend - c;
+                    const uint32_t run = ahead ? (uint32_t)__builtin_ctzll(ahead) : 64u;
+                    const uint32_t nlit = run < left ? run : left;
+                    marks |= (nlit >= 64u ? ~0ull : ((1ull << nlit) - 1ull)) << li;
+                    c += nlit;
+                    continue;
+                }
+                if (((isext >> li) & 1ull) == 0ull) {
+                    marks |= 1ull << li;
+                    c += 1u + (uint32_t)((s0 >> li) & 1ull) + 2u * (uint32_t)((s1 >> li) & 1ull)
+                            + 4u * (uint32_t)((s2 >> li) & 1ull);
+                    continue;
+                }
+                // ---- extended match (:411-431): flush what is marked, then this token
+                PROF_COUNT(8, 1);
+                br_emit_chunk(s, L.bits, lane, marks, r, byte);
+                marks = 0;
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)li) & kWindow;
+                if (off <= kShortMax) br_put(s, L.bits, lane, (((3u << 7) | off) << 4) | 0xFu, 13);
+                else                  br_put(s, L.bits, lane, (((2u << 11) | off) << 4) | 0xFu, 17);
+                c += kTokenMax;
                 bool more = true;
-                while (more) {
+                while (more) {                               // up to 60 bytes = 4 nibbles per round
                     chain_refill(L, src, n, src16, lane, loaded, c + 64);
-                    // keep the chains current while c runs ahead: build every batch that is
-                    // now wholly behind c (its bytes must still be in the ring)
+                    // keep the chains current while c runs ahead of the built range: every
+                    // batch now wholly behind c is inserted while its bytes are in the ring
                     while (next + 128 <= c) {
-                        uint32_t u0, u1, u2;
-                        chain_build(L, next, n, lane, u0, u1, u2);
+                        chain_build(L, next, n, lane);
                         next += 64;
                     }
                     const uint32_t rem = n - c;
@@ -499,17 +708,26 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
                     const uint64_t stopmask = __ballot(differs) | (1ull << span);
                     const uint32_t m = uniform((uint32_t)__builtin_ctzll(stopmask));  // equal bytes <= span
                     c += m;
-                    for (uint32_t k = m / kNibbleMax; k > 0; k--) sink_put(s, L.stage, lane, kNibbleMax, 4);
+                    const uint32_t full = m / kNibbleMax;                             // nibbles of 15
+                    if (full) br_put(s, L.bits, lane, (1u << (4 * full)) - 1u, 4 * full);
                     // 60 equal bytes = four full nibbles and the match may go on; anything
                     // shorter ends it with a last nibble of 0..14 (0 when it ended on a
                     // multiple of 15 or at the end of the input)
                     more = (m == 60u);
-                    if (!more) sink_put(s, L.stage, lane, m % kNibbleMax, 4);
+                    if (!more) br_put(s, L.bits, lane, m % kNibbleMax, 4);
+                    if (s.flushed >= s.cap) more = false;
                 }
             }
+            PROF_T1B(10);
+            PROF_T0C;
+            br_emit_chunk(s, L.bits, lane, marks, r, byte);
+            PROF_T1C(11);
         }
+        PROF_MARK(3);
+        PROF_COUNT(7, 1);
     }
-    sink_finish(s, L.stage, lane, &out_len[b]);
+    br_finish(s, L.bits, lane, &out_len[b]);
+    PROF_DONE;
 }
 
 // ---------------------------------------------------------------------------------
@@ -534,7 +752,7 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
 {
     __shared__ DecLds lds[kWavesPerWG];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv   = threadIdx.x >> 6;
+    const uint32_t wv   = uniform(threadIdx.x >> 6);   // wave-uniform, and the compiler knows it
     const uint32_t b    = blockIdx.x * kWavesPerWG + wv;
     if (b >= nblocks) return;
 
@@ -770,7 +988,7 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
     else
-        hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+        hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(nblocks), dim3(64), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
     return (int)hipGetLastError();

@@ -8,23 +8,23 @@
 
 __global__ void probe(const uint32_t *addr, uint32_t *bad_max, uint32_t *bad_xchg, uint32_t npat)
 {
-    __shared__ uint32_t tab[64 * 4];
+    __shared__ uint32_t tab[2048 * 4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *t = tab + wv * 64;
+    uint32_t *t = tab + wv * 2048;
     for (uint32_t pat = blockIdx.x * 4 + wv; pat < npat; pat += gridDim.x * 4) {
-        const uint32_t a = addr[pat * 64 + lane] & 63;
+        const uint32_t a = addr[pat * 64 + lane] & 2047;
         // expected: nearest lower lane with the same address (+1), else 0
         uint32_t expect = 0;
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t al = __shfl((int)a, (int)l, 64);
             if (l < lane && al == a) expect = l + 1;
         }
-        t[lane] = 0;
+        t[a] = 0;
         __builtin_amdgcn_wave_barrier();
         const uint32_t got = atomicMax(&t[a], lane + 1);
         __builtin_amdgcn_wave_barrier();
         if (got != expect) atomicAdd(bad_max, 1);
-        t[lane] = 0;
+        t[a] = 0;
         __builtin_amdgcn_wave_barrier();
         const uint32_t got2 = atomicExch(&t[a], lane + 1);
         __builtin_amdgcn_wave_barrier();
@@ -42,7 +42,12 @@ int main()
         for (uint32_t l = 0; l < 64; l++) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             uint32_t v = (uint32_t)(x >> 20);
-            if (mode < 7) v &= (1u << mode) - 1; else v = l / 5;
+            // few distinct addresses; same-bank strides (x32, x64 dwords); random; runs
+            if (mode < 4) v &= (1u << (mode + 1)) - 1;
+            else if (mode == 4) v = (v & 7) * 32;
+            else if (mode == 5) v = (v & 15) * 64 + ((v >> 8) & 1);
+            else if (mode == 6) v &= 2047;
+            else v = (l / 5) * 33;
             h[p * 64 + l] = v;
         }
     }
