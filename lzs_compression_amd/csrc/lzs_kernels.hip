@@ -731,6 +731,485 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
 }
 
 // ---------------------------------------------------------------------------------
+// lzs_compress() per block, variant "wg" (the default): the same algorithm as "chain",
+// but ONE 256-THREAD WORKGROUP PER BLOCK.  The four waves share a single set of LDS tables
+// (ring, heads, links), which quadruples the waves a CU can hold for a given LDS budget,
+// and every phase is lane-parallel over 256 threads, separated by workgroup barriers:
+//   BUILD   each hash bucket is owned by one wave (bucket & 3), so the ordered-exchange
+//           chaining stays inside one wave instruction stream; positions inside a run of
+//           one byte value (same byte before, 13 equal bytes ahead) are not inserted at all
+//           -- they can only ever win as offset 1, which every search checks first;
+//   SEARCH  the four waves pull positions from one shared counter; a match that fills the
+//           first length code is measured on to <= 59 more bytes so that its token is
+//           complete; longer ones are left "open";
+//   PARSE   the greedy chain of token starts (lzs-compression.c:301-447) is found by pointer
+//           jumping over next[i] = i + bytes consumed at i: 10 doubling rounds mark every
+//           token start of the pool, no serial chase;
+//   PACK    marked tokens are encoded by their owning threads, a workgroup prefix sum of
+//           the bit widths places them, and complete 256-byte quarters of the bit ring go
+//           out as coalesced stores.  Only open matches (long runs) are finished by wave 0
+//           alone, 60 bytes per step.
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kWgThreads  = 256;
+constexpr uint32_t kWgPool     = 512;
+constexpr uint32_t kWgLinkN    = 2560;            // 40 x 64 >= 2047 + kWgPool
+constexpr uint32_t kWgBitWords = 256;             // 8192-bit ring, quarters of 2048 bits
+constexpr uint32_t kOpen       = 1023;            // jump code of an open match
+constexpr uint32_t kExtOpen    = 63;              // extension code of an open match
+constexpr uint32_t kExtMax     = 59;              // longest extension resolved in SEARCH
+
+struct __attribute__((aligned(16))) BlkLds {
+    uint32_t ring[kRingWords + 4];                // +16 B mirror of ring[0..15]
+    uint32_t head3[kHead3];
+    uint32_t head2[kHead2];
+    uint16_t link3[kWgLinkN];
+    uint16_t link2[kWgLinkN];
+    uint32_t res[kWgPool];                        // off | len << 11 | ext << 15
+    uint16_t jmp[2][kWgPool];                     // pointer-jumping tables (double buffered)
+    uint32_t marks[kWgPool / 32];                 // token starts of the pool
+    uint32_t bits[kWgBitWords];                   // output bit ring
+    uint32_t chunk_bits[8];
+    uint32_t nextp;                               // SEARCH work counter
+    uint32_t exit_to;                             // where the token chain leaves the pool
+    uint32_t open_pos;
+    uint32_t bcast[8];
+};
+
+__device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) % 40u) * 64u; }
+
+__device__ __forceinline__ uint32_t lcp12(uint32_t x0, uint32_t x1, uint32_t x2)
+{
+    const uint32_t e0 = eq_bytes(x0), e1 = eq_bytes(x1), e2 = eq_bytes(x2);
+    return e0 + (e0 == 4 ? e1 + (e1 == 4 ? e2 : 0u) : 0u);
+}
+
+// OR `width` (1..32) bits of `value`, MSB first, at bit offset `at` of a ring of `words` words.
+__device__ __forceinline__ void bits_or(uint32_t *ring, uint32_t words, uint32_t at, uint32_t value, uint32_t width)
+{
+    const uint32_t sh = at & 31u, d = (at >> 5) & (words - 1);
+    const uint64_t v = (uint64_t)value << (64u - sh - width);
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    __hip_atomic_fetch_or(&ring[d], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lo) __hip_atomic_fetch_or(&ring[(d + 1) & (words - 1)], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Output state: wave-uniform and identical in all four waves.
+struct WgOut {
+    uint32_t flushed;    // bytes handed to HBM (multiple of 256)
+    uint32_t head;       // bits appended past `flushed`
+    uint8_t *dst;
+    uint32_t cap;
+    bool     aligned4;
+};
+
+__device__ __forceinline__ uint32_t wg_bit_at(const WgOut &o) { return ((o.flushed << 3) + o.head) & 8191u; }
+
+// Store one complete quarter (2048 bits) of the ring from the calling wave and clear it.
+__device__ __forceinline__ void wg_store_quarter(const WgOut &o, BlkLds &L, uint32_t lane)
+{
+    const uint32_t slot = ((o.flushed >> 8) & 3u) * 64u + lane;
+    const uint32_t v = __builtin_bswap32(L.bits[slot]);
+    L.bits[slot] = 0;
+    const uint32_t at = o.flushed + 4 * lane;
+    if (o.aligned4 && at + 4 <= o.cap) {
+        *reinterpret_cast<uint32_t *>(o.dst + at) = v;
+    } else {
+        for (uint32_t k = 0; k < 4; k++)
+            if (at + k < o.cap) o.dst[at + k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
+// ---- helpers used by wave 0 alone while it finishes an open match
+__device__ __forceinline__ void wave_refill(BlkLds &L, const uint8_t *src, uint32_t n, bool src16,
+                                            uint32_t lane, uint32_t &loaded, uint32_t need)
+{
+    while (loaded < n && loaded < need) {
+        const uint32_t p = loaded + 16 * lane;
+        const uint4 v = load16(src, p, n, src16);
+        const uint32_t at = (p & kRingMask) >> 2;
+        *reinterpret_cast<uint4 *>(&L.ring[at]) = v;
+        if (at == 0) *reinterpret_cast<uint4 *>(&L.ring[kRingWords]) = v;
+        loaded += kTile;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Insert the 64 positions starting at B.  `wave` < 4: only buckets owned by that wave
+// (called by all four waves); wave == 4: every bucket (called by one wave alone).
+__device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, uint32_t lane, uint32_t wave)
+{
+    const uint32_t p = B + lane;
+    const uint32_t a = (p & kRingMask) >> 2, sh = p & 3;
+    const uint32_t d0 = L.ring[a], d1 = L.ring[a + 1], d2 = L.ring[a + 2], d3 = L.ring[a + 3], d4 = L.ring[a + 4];
+    const uint32_t t0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t t1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t t2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    const uint32_t t3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    const uint32_t splat = (t0 & 0xFFu) * 0x01010101u;
+    // Interior of a run: the same byte before, and 13 equal bytes ahead.  Such a position is
+    // dominated by p+1 as a candidate for every later position, and its own search ends at
+    // offset 1 (full cap), so it is neither inserted nor does it need a link.
+    const bool deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
+                      p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
+    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 21;
+    const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 7) & (kHead2 - 1);
+    const uint32_t slot = wg_slot_base(B) + lane;
+    if (wave == 4 || (h3 & 3u) == wave) {
+        uint32_t d = kNoLink;
+        if (p + 2 < n && !deep) {
+            const uint32_t old = __hip_atomic_exchange(&L.head3[h3], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            d = p - old < kNoLink ? p - old : kNoLink;
+        }
+        L.link3[slot] = (uint16_t)d;
+    }
+    if (wave == 4 || (h2 & 3u) == wave) {
+        uint32_t d = kNoLink;
+        if (p + 1 < n && !deep) {
+            const uint32_t old = __hip_atomic_exchange(&L.head2[h2], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            d = p - old < kNoLink ? p - old : kNoLink;
+        }
+        L.link2[slot] = (uint16_t)d;
+    }
+}
+
+// SEARCH: every wave pulls positions of [.., pend) from L.nextp until the pool is empty.
+__device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend, uint32_t n, uint32_t lane)
+{
+    const uint32_t slot0 = wg_slot_base(Pb);
+    bool busy = false, three = false, pool_done = false;
+    uint32_t p = Pb, t0 = 0, t1 = 0, t2 = 0, lim = 0, reach = 0, myslot = slot0, first2 = kNoLink;
+    uint32_t cum = 0, dist = kNoLink, best_len = 0, best_off = 0;
+    for (;;) {
+        const uint64_t idle = __ballot(!busy);
+        const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
+        if (!pool_done && (nidle >= kRefillMin || nidle == 64u)) {
+            uint32_t basep = 0;
+            if (lane == 0) basep = __hip_atomic_fetch_add(&L.nextp, nidle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            basep = uniform(basep);
+            pool_done = basep + nidle >= pend;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                  __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t np = basep + rank;
+            const bool take = !busy && np < pend;
+            const uint32_t pp = take ? np : p;                          // every lane reads in range
+            uint32_t n0, n1, n2;
+            ringm_read12(L.ring, pp, n0, n1, n2);
+            const uint32_t before = ring_byte(L.ring, pp - 1u);
+            uint32_t sl = slot0 + (pp - Pb);
+            sl = sl >= kWgLinkN ? sl - kWgLinkN : sl;
+            const uint32_t l3 = L.link3[sl], l2 = L.link2[sl];
+            const uint32_t nlim = n - pp < kSearchCap ? n - pp : kSearchCap;
+            // offset 1 first: common prefix of the text with itself shifted by one byte
+            uint32_t len1 = lcp12(n0 ^ ((n0 << 8) | before), n1 ^ ((n1 << 8) | (n0 >> 24)), n2 ^ ((n2 << 8) | (n1 >> 24)));
+            len1 = len1 < nlim ? len1 : nlim;
+            const bool seeded = pp >= 1u && len1 >= 2u;
+            const bool capped = seeded && len1 == nlim;                 // nothing nearer or longer exists
+            p = pp; myslot = sl;
+            t0 = take ? n0 : t0; t1 = take ? n1 : t1; t2 = take ? n2 : t2;
+            lim = take ? nlim : lim;
+            reach = take ? (pp < kWindow ? pp : kWindow) : reach;
+            three = take ? (nlim >= 3 && !capped) : three;
+            first2 = take ? (nlim >= 2 ? l2 : kNoLink) : first2;
+            dist = take ? (capped ? kNoLink : (nlim >= 3 ? l3 : (nlim >= 2 ? l2 : kNoLink))) : dist;
+            cum = take ? 0u : cum;
+            best_len = take ? (seeded ? len1 : 0u) : best_len;
+            best_off = take ? (seeded ? 1u : 0u) : best_off;
+            busy = busy || take;
+        }
+        if (__ballot(busy) == 0ull) {
+            if (pool_done) break;
+            continue;
+        }
+        const uint32_t cum2 = cum + dist;
+        const bool inwin = busy && cum2 <= reach;
+        uint32_t w0, w1, w2;
+        ringm_read12(L.ring, p - (inwin ? cum2 : 0u), w0, w1, w2);
+        int32_t at = (int32_t)myslot - (int32_t)(inwin ? cum2 : 0u);
+        at = at < 0 ? at + (int32_t)kWgLinkN : at;
+        const uint32_t nd = three ? L.link3[at] : L.link2[at];
+        uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
+        len = len < lim ? len : lim;
+        // 3-byte chain: first strictly longer match >= 3 wins, the cap ends the walk (:337-345);
+        // 2-byte chain: the first verified candidate is the answer
+        const bool better = three ? (len > best_len && len >= 3u) : (len >= 2u && best_len < 2u);
+        const bool takeit = inwin && better;
+        best_len = takeit ? len : best_len;
+        best_off = takeit ? cum2 : best_off;
+        const bool ended = !inwin || (three ? len == lim : len >= 2u);
+        // nothing >= 2 so far and the 3-byte chain is exhausted: restart on the 2-byte chain
+        const bool fallback = busy && ended && three && best_len < 2u;
+        const bool finish = busy && ended && !fallback;
+        cum = fallback ? 0u : cum2;
+        dist = fallback ? first2 : nd;
+        three = three && !fallback;
+        if (finish) {
+            // a match that fills the search cap may run on: measure it (up to kExtMax more
+            // than the 8 of the first code) so the token is complete (:417-431)
+            uint32_t ext = best_len >= kTokenMax ? best_len - kTokenMax : 0u;
+            if (best_len == kSearchCap && n - p > kSearchCap) {
+                const uint32_t room = n - p < kTokenMax + kExtMax + 1 ? n - p : kTokenMax + kExtMax + 1;
+                uint32_t total = kSearchCap;
+                for (;;) {
+                    uint32_t a0, a1, a2, b0, b1, b2;
+                    ringm_read12(L.ring, p + total, a0, a1, a2);
+                    ringm_read12(L.ring, p + total - best_off, b0, b1, b2);
+                    uint32_t e = lcp12(a0 ^ b0, a1 ^ b1, a2 ^ b2);
+                    e = e < room - total ? e : room - total;
+                    total += e;
+                    if (e < 12u || total >= room) break;
+                }
+                ext = total - kTokenMax;
+            }
+            const uint32_t code = ext > kExtMax ? kExtOpen : ext;
+            L.res[p - Pb] = best_off | (best_len << 11) | (code << 15);
+        }
+        busy = busy && !finish;
+    }
+}
+
+__global__ __launch_bounds__(kWgThreads)
+void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
+                                   uint32_t *__restrict__ out_len,
+                                   const uint8_t *__restrict__ in, size_t in_stride,
+                                   const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
+                                   uint32_t nblocks)
+{
+    __shared__ BlkLds L;
+    const uint32_t tid  = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = uniform(tid >> 6);
+    const uint32_t b    = blockIdx.x;
+    if (b >= nblocks) return;
+
+    const uint8_t *src = in + (size_t)b * in_stride;
+    const uint32_t n   = in_len ? in_len[b] : in_len_uniform;
+    const bool src16   = ((uintptr_t)src & 15u) == 0;
+    const bool src4    = ((uintptr_t)src & 3u) == 0;
+
+    WgOut o;
+    o.flushed = 0; o.head = 0;
+    o.dst = out + (size_t)b * out_stride;
+    o.cap = out_cap;
+    o.aligned4 = ((uintptr_t)o.dst & 3u) == 0;
+
+    for (uint32_t i = tid; i < kHead3; i += kWgThreads) L.head3[i] = ~0u;
+    for (uint32_t i = tid; i < kHead2; i += kWgThreads) L.head2[i] = ~0u;
+    L.bits[tid] = 0;
+    __syncthreads();
+
+    uint32_t c = 0;          // start of the next token
+    uint32_t loaded = 0;     // ring holds [loaded-4096, loaded)
+    uint32_t next = 0;       // next batch of 64 positions to build
+
+    while (c < n && o.flushed < o.cap) {
+        // ---- REFILL (256 threads x 4 B per KiB) for the batches up to the end of the pool
+        uint32_t Pb = next;
+        while (Pb + 64 <= c) Pb += 64;                        // batches wholly behind c: built, not searched
+        const uint32_t nup = (n + 63u) & ~63u;
+        const uint32_t Pe = Pb + kWgPool < nup ? Pb + kWgPool : nup;
+        const uint32_t need = (Pe > c ? Pe : c) + 96;
+        while (loaded < n && loaded < need) {
+            const uint32_t p = loaded + 4 * tid;
+            uint32_t v = 0;
+            if (p + 4 <= n && src4) {
+                v = *reinterpret_cast<const uint32_t *>(src + p);
+            } else {
+                for (uint32_t k = 0; k < 4; k++)
+                    if (p + k < n) v |= (uint32_t)src[p + k] << (8 * k);
+            }
+            const uint32_t at = (p & kRingMask) >> 2;
+            L.ring[at] = v;
+            if (at < 4) L.ring[kRingWords + at] = v;
+            loaded += kTile;
+        }
+        __syncthreads();
+
+        // ---- BUILD [next, Pe): every wave walks all batches, inserting into its own buckets
+        for (uint32_t B = next; B < Pe; B += 64) wg_build64(L, B, n, lane, wave);
+        next = Pe;
+        const uint32_t pend = Pe < n ? Pe : n;
+        if (tid == 0) L.nextp = c > Pb ? c : Pb;
+        __syncthreads();
+
+        // ---- SEARCH
+        wg_search(L, Pb, pend, n, lane);
+        __syncthreads();
+
+        // ---- PARSE + PACK; repeated after each open match that ends inside the pool
+        const uint32_t npos = pend - Pb;
+        while (c < pend && o.flushed < o.cap) {
+            const uint32_t entry = c - Pb;
+            // next[i] for this thread's two positions (chunk `wave` and chunk 4 + `wave`)
+            uint32_t idx[2], nx[2], rr[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t i = 256u * h + 64u * wave + lane;
+                const uint32_t r = L.res[i];
+                const uint32_t len = (r >> 11) & 15u, ext = r >> 15;
+                uint32_t to = i + (len < 2u ? 1u : (len < kTokenMax ? len : kTokenMax + ext));
+                if (len >= kTokenMax && ext == kExtOpen) to = kOpen;
+                idx[h] = i; nx[h] = to; rr[h] = r;
+                L.jmp[0][i] = (uint16_t)to;
+            }
+            if (tid < kWgPool / 32) L.marks[tid] = 0;
+            __syncthreads();
+            if (tid == 0) {
+                L.marks[entry >> 5] = 1u << (entry & 31u);
+                L.exit_to = kOpen;
+                L.open_pos = 0;
+            }
+            __syncthreads();
+            // pointer jumping: after round k every token start within 2^(k+1) tokens of the
+            // entry is marked; jumps that leave the pool (>= npos) or hit an open match are
+            // absorbing and identify where the chain ends
+#pragma unroll 1
+            for (uint32_t k = 0; k < 10; k++) {
+                const uint32_t cur = k & 1u;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t i = idx[h];
+                    const uint32_t j = L.jmp[cur][i];
+                    const bool marked = i < npos && ((L.marks[i >> 5] >> (i & 31u)) & 1u);
+                    if (marked) {
+                        if (j < npos) __hip_atomic_fetch_or(&L.marks[j >> 5], 1u << (j & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else L.exit_to = j;
+                    }
+                    L.jmp[cur ^ 1u][i] = (uint16_t)(j < npos ? L.jmp[cur][j] : j);
+                }
+                __syncthreads();
+            }
+            // the open match (if the chain ends in one) identifies itself
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (idx[h] < npos && nx[h] == kOpen && ((L.marks[idx[h] >> 5] >> (idx[h] & 31u)) & 1u))
+                    L.open_pos = idx[h];
+            // ---- PACK: encode my marked tokens (formats: lzs-compression.c:365-431)
+            uint32_t headv[2], headw[2], tailv[2], tailw[2], incl[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t i = idx[h], r = rr[h];
+                const bool mine = i < npos && nx[h] != kOpen && ((L.marks[i >> 5] >> (i & 31u)) & 1u);
+                const uint32_t len = (r >> 11) & 15u, ext = r >> 15, off = r & kWindow;
+                uint32_t hv = ring_byte(L.ring, Pb + i) & 0xFFu, hw = 9, tv = 0, tw = 0;      // 0 bbbbbbbb
+                if (len >= 2u) {
+                    const uint32_t ov = off <= kShortMax ? ((3u << 7) | off) : ((2u << 11) | off);
+                    const uint32_t ow = off <= kShortMax ? 9u : 13u;
+                    const uint32_t first = len < kTokenMax ? len : kTokenMax;
+                    const uint32_t lv = first <= 4 ? first - 2 : 0xCu + (first - 5);
+                    const uint32_t lw = first <= 4 ? 2u : 4u;
+                    hv = (ov << lw) | lv;
+                    hw = ow + lw;
+                    if (len >= kTokenMax) {                       // nibbles: 15 15 .. last
+                        const uint32_t full = ext / kNibbleMax;
+                        tv = (((1u << (4 * full)) - 1u) << 4) | (ext % kNibbleMax);
+                        tw = 4 * (full + 1);
+                    }
+                }
+                headv[h] = hv; headw[h] = mine ? hw : 0u; tailv[h] = tv; tailw[h] = mine ? tw : 0u;
+                incl[h] = wave_inclusive_sum(headw[h] + tailw[h]);
+                if (lane == 63) L.chunk_bits[4 * h + wave] = incl[h];
+            }
+            __syncthreads();
+            uint32_t before[2] = {0, 0}, total = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const uint32_t cb = L.chunk_bits[q];
+                if (q < wave) before[0] += cb;
+                if (q < 4 + wave) before[1] += cb;
+                total += cb;
+            }
+            const uint32_t at0 = wg_bit_at(o);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t wsum = headw[h] + tailw[h];
+                if (wsum) {
+                    const uint32_t at = at0 + before[h] + incl[h] - wsum;
+                    bits_or(L.bits, kWgBitWords, at & 8191u, headv[h], headw[h]);
+                    if (tailw[h]) bits_or(L.bits, kWgBitWords, (at + headw[h]) & 8191u, tailv[h], tailw[h]);
+                }
+            }
+            const uint32_t chain_end = L.exit_to;
+            const uint32_t open_at = L.open_pos;
+            o.head += total;
+            __syncthreads();
+            // complete quarters go out, one wave each
+            while (o.head >= 2048u) {
+                if (wave == ((o.flushed >> 8) & 3u)) wg_store_quarter(o, L, lane);
+                o.flushed += 256u;
+                o.head -= 2048u;
+            }
+            __syncthreads();
+
+            if (chain_end != kOpen) {
+                c = Pb + chain_end;                            // >= pend
+            } else {
+                // ---- open match at Pb + open_at: wave 0 finishes it alone (:417-431)
+                if (wave == 0) {
+                    const uint32_t off = L.res[open_at] & kWindow;
+                    if (lane == 0) {
+                        if (off <= kShortMax) bits_or(L.bits, kWgBitWords, wg_bit_at(o), (((3u << 7) | off) << 4) | 0xFu, 13);
+                        else                  bits_or(L.bits, kWgBitWords, wg_bit_at(o), (((2u << 11) | off) << 4) | 0xFu, 17);
+                    }
+                    o.head += off <= kShortMax ? 13u : 17u;
+                    c = Pb + open_at + kTokenMax;
+                    bool more = true;
+                    while (more) {                             // up to 60 bytes = 4 nibbles per round
+                        while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
+                        if (o.flushed >= o.cap) break;
+                        wave_refill(L, src, n, src16, lane, loaded, c + 64);
+                        // keep the chains current while c runs ahead of the built range
+                        while (next + 128 <= c) {
+                            wg_build64(L, next, n, lane, 4);
+                            next += 64;
+                        }
+                        const uint32_t rem = n - c;
+                        const uint32_t span = rem < 60u ? rem : 60u;
+                        const bool differs = lane < span &&
+                                             ring_byte(L.ring, c + lane) != ring_byte(L.ring, c + lane - off);
+                        const uint64_t stopmask = __ballot(differs) | (1ull << span);
+                        const uint32_t m = uniform((uint32_t)__builtin_ctzll(stopmask));   // equal bytes <= span
+                        c += m;
+                        const uint32_t full = m / kNibbleMax;
+                        more = (m == 60u);
+                        // nibbles of 15, then (unless 60 bytes matched and the run may go on)
+                        // the closing nibble 0..14
+                        const uint32_t v = more ? 0xFFFFu : ((((1u << (4 * full)) - 1u) << 4) | (m % kNibbleMax));
+                        const uint32_t wbits = more ? 16u : 4 * (full + 1);
+                        if (lane == 0) bits_or(L.bits, kWgBitWords, wg_bit_at(o), v, wbits);
+                        o.head += wbits;
+                    }
+                    while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
+                    if (lane == 0) {
+                        L.bcast[0] = c; L.bcast[1] = loaded; L.bcast[2] = next;
+                        L.bcast[3] = o.flushed; L.bcast[4] = o.head;
+                    }
+                }
+                __syncthreads();
+                c = L.bcast[0]; loaded = L.bcast[1]; next = L.bcast[2];
+                o.flushed = L.bcast[3]; o.head = L.bcast[4];
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- end marker 1 1 0000000, zero pad to a byte, drain (:449-466)
+    if (wave == 0) {
+        if (lane == 0) bits_or(L.bits, kWgBitWords, wg_bit_at(o), 0x180u, 9);
+        o.head = (o.head + 9u + 7u) & ~7u;
+        while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nbytes = o.head >> 3;
+        for (uint32_t i = lane; i < nbytes; i += 64) {
+            const uint32_t bit = ((o.flushed << 3) + 8 * i) & 8191u;
+            const uint32_t v = (L.bits[bit >> 5] >> (24u - (bit & 24u))) & 0xFFu;
+            if (o.flushed + i < o.cap) o.dst[o.flushed + i] = (uint8_t)v;
+        }
+        const uint32_t total = o.flushed + nbytes;
+        if (lane == 0) out_len[b] = total < o.cap ? total : o.cap;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // lzs_decompress() per block.  reference lzs-decompression.c:156-412
 // One wave per stream: the token parse is wave-uniform, match copies are lane-parallel
 // (lane i produces byte i of the copy; overlapping copies replicate with period `off`).
@@ -978,17 +1457,22 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
 {
     if (nblocks == 0) return 0;
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
-    // LZS_KERNEL=scan selects the brute-force variant (A/B and cross-checking); default "chain"
-    static const bool use_scan = [] {
+    // LZS_KERNEL selects a variant for A/B runs and cross-checks: "wg" (default, one
+    // workgroup per block), "chain" (one wave per block), "scan" (brute force)
+    static const int variant = [] {
         const char *v = getenv("LZS_KERNEL");
-        return v && v[0] == 's';
+        return !v ? 0 : (v[0] == 's' ? 2 : (v[0] == 'c' ? 1 : 0));
     }();
-    if (use_scan)
+    if (variant == 2)
         hipLaunchKernelGGL(lzs_compress_blocks_scan_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
-    else
+    else if (variant == 1)
         hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(nblocks), dim3(64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+    else
+        hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
     return (int)hipGetLastError();

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Development aid: decode two LZS streams into token lists and show where they first differ."""
+import sys, os
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def tokens(stream):
+    bits = "".join(f"{b:08b}" for b in stream)
+    i, pos, out = 0, 0, []
+    while i < len(bits):
+        if bits[i] == "0":
+            out.append((pos, 0, 1)); i += 9; pos += 1; continue
+        if bits[i + 1] == "1":
+            off = int(bits[i + 2:i + 9], 2); i += 9
+            if off == 0:
+                break
+        else:
+            off = int(bits[i + 2:i + 13], 2); i += 13
+        code = bits[i:i + 4]
+        if code[:2] != "11":
+            ln = 2 + int(code[:2], 2); i += 2
+        else:
+            ln = 5 + int(code[2:], 2); i += 4
+            if ln == 8:
+                while True:
+                    nb = int(bits[i:i + 4], 2); i += 4; ln += nb
+                    if nb != 15:
+                        break
+        out.append((pos, off, ln)); pos += ln
+    return out
+
+
+if __name__ == "__main__":
+    import numpy as np
+    import oracle
+    import lzs_compression_amd as lzs
+    from lzs_compression_amd import workload
+    cls, blk = sys.argv[1], int(sys.argv[2])
+    data = workload.fill(cls, 1, first_block=blk)[0].tobytes()
+    want = tokens(oracle.oracle().compress(data))
+    got = tokens(lzs.compress(data))
+    for k, (a, b) in enumerate(zip(want, got)):
+        if a != b:
+            print("first differing token", k, "want", a, "got", b)
+            print("context want", want[max(0, k - 3):k + 3])
+            print("context got ", got[max(0, k - 3):k + 3])
+            p = a[0]
+            print("data around", p, data[max(0, p - 40):p + 24].hex())
+            break
+    else:
+        print("token lists equal" if len(want) == len(got) else f"lengths differ {len(want)} {len(got)}")
