@@ -32,12 +32,36 @@ BLOCK = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level table)
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: the smaller of the affinity mask and the
+    cgroup CPU quota (the GPU box advertises 256 CPUs but grants a 16-CPU quota)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def pmc_traffic(cls: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None.
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide streaming reads."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))[cls]
+        return {"hbm_bytes": rec["fetch_bytes_corrected"] + rec["write_bytes"], **rec}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(blocks_host: np.ndarray, gpu_len: np.ndarray, gpu_slots) -> dict:
     """The reference C compressor (oracle/_ref, kind "reference") or, where it did not
     travel, our C restatement (kind "port"), one block per task on the host cores, on a
     bounded sample of the same workload.  Also cross-checks the GPU output on that sample."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     kind = "reference" if oracle.have_ref() else "port"
     codec = oracle.ref() if kind == "reference" else oracle.oracle()
     # size the sample for roughly 15 core-seconds of work: probe 64 blocks on one thread first
@@ -53,6 +77,7 @@ def cpu_baseline(blocks_host: np.ndarray, gpu_len: np.ndarray, gpu_slots) -> dic
         for b in range(0, nsample, max(1, nsample // 64)):
             exact = exact and g[b, :out_len[b]].tobytes() == out[b, :out_len[b]].tobytes()
     return {"value": nsample * BLOCK / secs / 1e9, "unit": "GB/s", "cores": cores, "kind": kind,
+            "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity/cgroup quota)",
             "one_core_GBps": one_core,
             "sample": f"first {nsample} of the same 64 KiB blocks ({nsample * BLOCK >> 20} MiB), "
                       f"one block per task, {cores} threads",
@@ -120,12 +145,31 @@ def main() -> None:
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
+    # N > 1: one compressed-output gather to rank 0 (compaction + RCCL gather-v), outside
+    # the timed steps and reported separately -- the compute path itself has no collective
+    gather = None
+    if dist is not None:
+        from lzs_compression_amd import sharding
+        try:
+            barrier()
+            g0 = time.perf_counter()
+            dense, offsets = lzs.compact(slots, lens)
+            nbytes = int(offsets[-1].item())
+            got, counts = sharding.gather_streams(dense, nbytes)
+            barrier()
+            gsec = time.perf_counter() - g0
+            gather = {"ms": gsec * 1e3, "bytes": int(sum(counts)), "GBps": sum(counts) / gsec / 1e9}
+            del dense, got
+        except Exception as e:          # the headline number must survive a gather failure
+            gather = {"error": repr(e)}
+
     total_in = world * nb * BLOCK * args.steps
     lens_h = lens.cpu().numpy()
     ratio = float(lens_h.sum()) / (nb * BLOCK)
 
     if rank == 0:
         avg_ms = float(np.mean(kernel_ms))
+        traffic = pmc_traffic(args.workload) if nb == 16384 else None
         in_bytes = nb * BLOCK
         algo_bytes = in_bytes + int(lens_h.sum()) + 4 * nb
         achieved = in_bytes / (avg_ms * 1e-3) / 1e9
@@ -148,13 +192,16 @@ def main() -> None:
                        "sharding": f"blocks/{world} per rank, no data-path collective",
                        "compression_ratio": ratio},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "lzs_compress_blocks_kernel",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic,
+                         "kernel": "lzs_compress_blocks_wg_kernel",
                          "algorithmic_bytes_per_launch": {"read_input": in_bytes,
                                                           "total_read_plus_written": algo_bytes},
                          "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
                          "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
         }
+        if gather is not None:
+            result["compressed_output_gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(host, lens_h, slots)
         print(json.dumps(result), flush=True)

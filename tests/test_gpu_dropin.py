@@ -1,0 +1,20 @@
+"""Drop-in proof: the REFERENCE's own compression unit test (c/src/test/test-lzs.c, built by
+oracle/Makefile against OUR header and linked with OUR liblzs.so -> oracle/_ref/dropin-test-lzs)
+passes on the GPU: 507 incompressible prefixes and 1001 repeated-byte lengths, exact compressed
+sizes and round trips, all through the 4-argument lzs_compress()/lzs_decompress()."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+EXE = os.path.join(ROOT, "oracle", "_ref", "dropin-test-lzs")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/dropin-test-lzs was not built (needs /root/reference)")
+def test_reference_unit_test_passes_against_our_library():
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2 Tests 0 Failures 0 Ignored" in r.stdout, r.stdout
