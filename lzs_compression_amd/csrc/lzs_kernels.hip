@@ -424,7 +424,7 @@ __device__ __forceinline__ void br_finish(BitRing &e, uint32_t *words, uint32_t 
 #ifdef LZS_PROFILE
 // Diagnostic build only (tools/probes/prof_compress): per-phase cycle sums over all waves.
 __device__ unsigned long long lzs_prof[16];
-#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
 #define PROF_MARK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; } while (0)
 #define PROF_COUNT(i, v) do { prof_acc[i] += (v); } while (0)
 #define PROF_T0 unsigned long long prof_u = __builtin_readcyclecounter()
@@ -433,7 +433,7 @@ __device__ unsigned long long lzs_prof[16];
 #define PROF_T1B(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_v; } while (0)
 #define PROF_T0C unsigned long long prof_w = __builtin_readcyclecounter()
 #define PROF_T1C(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_w; } while (0)
-#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
+#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 16; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
@@ -873,7 +873,14 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
 }
 
 // SEARCH: every wave pulls positions of [.., pend) from L.nextp until the pool is empty.
-__device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend, uint32_t n, uint32_t lane)
+#ifdef LZS_PROFILE
+#define SEARCH_PROF_PARAMS , unsigned long long *prof_acc
+#define SEARCH_PROF_ARGS , prof_acc
+#else
+#define SEARCH_PROF_PARAMS
+#define SEARCH_PROF_ARGS
+#endif
+__device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend, uint32_t n, uint32_t lane SEARCH_PROF_PARAMS)
 {
     const uint32_t slot0 = wg_slot_base(Pb);
     bool busy = false, three = false, pool_done = false;
@@ -891,6 +898,8 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
                                   __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t np = basep + rank;
             const bool take = !busy && np < pend;
+            PROF_COUNT(9, 1);
+            PROF_COUNT(10, __builtin_popcountll(__ballot(take)));
             const uint32_t pp = take ? np : p;                          // every lane reads in range
             uint32_t n0, n1, n2;
             ringm_read12(L.ring, pp, n0, n1, n2);
@@ -899,27 +908,44 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
             sl = sl >= kWgLinkN ? sl - kWgLinkN : sl;
             const uint32_t l3 = L.link3[sl], l2 = L.link2[sl];
             const uint32_t nlim = n - pp < kSearchCap ? n - pp : kSearchCap;
-            // offset 1 first: common prefix of the text with itself shifted by one byte
-            uint32_t len1 = lcp12(n0 ^ ((n0 << 8) | before), n1 ^ ((n1 << 8) | (n0 >> 24)), n2 ^ ((n2 << 8) | (n1 >> 24)));
-            len1 = len1 < nlim ? len1 : nlim;
-            const bool seeded = pp >= 1u && len1 >= 2u;
+            // offset 1 first: common prefix of the text with itself shifted by one byte.  It
+            // can only reach 2 if the byte before equals the next two, which is rare in text:
+            // the 12-byte form is computed only when some lane needs it.
+            const bool maybe1 = take && pp >= 1u && ((n0 ^ ((n0 << 8) | before)) & 0xFFFFu) == 0;
+            uint32_t len1 = 0;
+            if (__any(maybe1)) {
+                len1 = lcp12(n0 ^ ((n0 << 8) | before), n1 ^ ((n1 << 8) | (n0 >> 24)), n2 ^ ((n2 << 8) | (n1 >> 24)));
+                len1 = len1 < nlim ? len1 : nlim;
+            }
+            const bool seeded = maybe1 && len1 >= 2u;
             const bool capped = seeded && len1 == nlim;                 // nothing nearer or longer exists
+            const uint32_t nreach = pp < kWindow ? pp : kWindow;
+            // chains that are empty inside the window are skipped here, not discovered by a step
+            const bool walk3 = nlim >= 3u && !capped && l3 <= nreach;
+            const bool walk2 = nlim >= 2u && !capped && !seeded && l2 <= nreach;
+            // no candidate anywhere: a literal, or the offset-1 match as it stands (a match that
+            // fills the 12-byte cap still goes through a step so that its extension is measured)
+            const bool instant = take && !walk3 && !walk2 && !(seeded && len1 == kSearchCap);
+            if (instant)
+                L.res[pp - Pb] = seeded ? (1u | (len1 << 11) | ((len1 >= kTokenMax ? len1 - kTokenMax : 0u) << 15)) : 0u;
             p = pp; myslot = sl;
             t0 = take ? n0 : t0; t1 = take ? n1 : t1; t2 = take ? n2 : t2;
             lim = take ? nlim : lim;
-            reach = take ? (pp < kWindow ? pp : kWindow) : reach;
-            three = take ? (nlim >= 3 && !capped) : three;
-            first2 = take ? (nlim >= 2 ? l2 : kNoLink) : first2;
-            dist = take ? (capped ? kNoLink : (nlim >= 3 ? l3 : (nlim >= 2 ? l2 : kNoLink))) : dist;
+            reach = take ? nreach : reach;
+            three = take ? walk3 : three;
+            first2 = take ? (walk2 ? l2 : kNoLink) : first2;
+            dist = take ? (walk3 ? l3 : (walk2 ? l2 : kNoLink)) : dist;
             cum = take ? 0u : cum;
             best_len = take ? (seeded ? len1 : 0u) : best_len;
             best_off = take ? (seeded ? 1u : 0u) : best_off;
-            busy = busy || take;
+            busy = busy || (take && !instant);
         }
         if (__ballot(busy) == 0ull) {
             if (pool_done) break;
             continue;
         }
+        PROF_COUNT(11, 1);
+        PROF_COUNT(8 + 4, __builtin_popcountll(__ballot(busy)));
         const uint32_t cum2 = cum + dist;
         const bool inwin = busy && cum2 <= reach;
         uint32_t w0, w1, w2;
@@ -1000,8 +1026,10 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     uint32_t c = 0;          // start of the next token
     uint32_t loaded = 0;     // ring holds [loaded-4096, loaded)
     uint32_t next = 0;       // next batch of 64 positions to build
+    PROF_DECL;
 
     while (c < n && o.flushed < o.cap) {
+        PROF_MARK(4);
         // ---- REFILL (256 threads x 4 B per KiB) for the batches up to the end of the pool
         uint32_t Pb = next;
         while (Pb + 64 <= c) Pb += 64;                        // batches wholly behind c: built, not searched
@@ -1023,6 +1051,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             loaded += kTile;
         }
         __syncthreads();
+        PROF_MARK(0);
 
         // ---- BUILD [next, Pe): every wave walks all batches, inserting into its own buckets
         for (uint32_t B = next; B < Pe; B += 64) wg_build64(L, B, n, lane, wave);
@@ -1030,10 +1059,13 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         const uint32_t pend = Pe < n ? Pe : n;
         if (tid == 0) L.nextp = c > Pb ? c : Pb;
         __syncthreads();
+        PROF_MARK(1);
 
         // ---- SEARCH
-        wg_search(L, Pb, pend, n, lane);
+        wg_search(L, Pb, pend, n, lane SEARCH_PROF_ARGS);
+        PROF_MARK(2);
         __syncthreads();
+        PROF_MARK(5);
 
         // ---- PARSE + PACK; repeated after each open match that ends inside the pool
         const uint32_t npos = pend - Pb;
@@ -1078,6 +1110,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                 }
                 __syncthreads();
             }
+            PROF_MARK(3);
             // the open match (if the chain ends in one) identifies itself
 #pragma unroll
             for (int h = 0; h < 2; h++)
@@ -1140,6 +1173,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             }
             __syncthreads();
 
+            PROF_MARK(6);
             if (chain_end != kOpen) {
                 c = Pb + chain_end;                            // >= pend
             } else {
@@ -1188,9 +1222,12 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                 c = L.bcast[0]; loaded = L.bcast[1]; next = L.bcast[2];
                 o.flushed = L.bcast[3]; o.head = L.bcast[4];
                 __syncthreads();
+                PROF_MARK(7);
             }
         }
+        PROF_COUNT(13, 1);
     }
+    if (wave == 0) { PROF_DONE; }
 
     // ---- end marker 1 1 0000000, zero pad to a byte, drain (:449-466)
     if (wave == 0) {

@@ -20,21 +20,19 @@ int main(int argc, char **argv)
         hipMemcpyToSymbol(HIP_SYMBOL(lzs_prof), zero, sizeof(zero));
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a);
-        hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(nb), dim3(64), 0, 0, d_out, stride, 73731u, d_len,
+        hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nb), dim3(256), 0, 0, d_out, stride, 73731u, d_len,
                            (const uint8_t *)d_in, (size_t)bl, (const uint32_t *)nullptr, bl, nb);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         unsigned long long p[16];
         hipMemcpyFromSymbol(p, HIP_SYMBOL(lzs_prof), sizeof(p));
-        const double tot = (double)(p[0] + p[1] + p[2] + p[3] + p[4]);
-        printf("class %u: %.2f ms (%.2f GB/s)\n", cls, ms, nb * 65536.0 / ms / 1e6);
-        printf("  cycles/byte/wave: refill %.1f build %.1f search %.1f parse %.1f other %.1f (sum %.1f)\n",
-               p[0] / (nb * 65536.0), p[1] / (nb * 65536.0), p[2] / (nb * 65536.0), p[3] / (nb * 65536.0),
-               p[4] / (nb * 65536.0), tot / (nb * 65536.0));
-        printf("  pools %llu, search iterations/pool %.1f, busy lanes/iteration %.1f\n", p[7],
-               (double)p[5] / p[7], (double)p[6] / p[5]);
-        printf("  extended tokens/pool %.2f; parse split, cycles/byte: chunk head %.1f, chase (incl. extended) %.1f, last emit %.1f\n",
-               (double)p[8] / p[7], p[9] / (nb * 65536.0), p[10] / (nb * 65536.0), p[11] / (nb * 65536.0));
+        const double nbytes = nb * 65536.0;
+        double tot = 0; for (int i = 0; i < 8; i++) tot += (double)p[i];
+        printf("class %u: %.2f ms (%.2f GB/s); wave-0 cycles per byte per workgroup:\n", cls, ms, nbytes / ms / 1e6);
+        printf("  refill %.1f  build %.1f  search %.1f  wait-for-other-waves %.1f  mark %.1f  pack %.1f  open-match %.1f  other %.1f  (sum %.1f), pools %llu\n",
+               p[0] / nbytes, p[1] / nbytes, p[2] / nbytes, p[5] / nbytes, p[3] / nbytes, p[6] / nbytes, p[7] / nbytes, p[4] / nbytes, tot / nbytes, p[13]);
+        printf("  wave 0 per pool: refill passes %.2f (positions taken %.1f), step iterations %.2f (busy lanes %.1f)\n",
+               (double)p[9] / p[13], (double)p[10] / p[13], (double)p[11] / p[13], (double)p[12] / (p[11] ? p[11] : 1));
     }
     return 0;
 }
