@@ -412,7 +412,7 @@ __device__ __forceinline__ void br_finish(BitRing &e, uint32_t *words, uint32_t 
 //              results and packs bits.
 // Positions swallowed by a long match are built but not searched.
 //
-// Chain storage, per wave, in LDS: head3[2048], head2[512] (latest position per hash),
+// Chain storage, per wave, in LDS: head3[1024], head2[512] (latest position per hash),
 // link3[2560], link2[2560] (per position, ring of 40 batches: distance to the previous
 // position with the same hash; anything > 2047 means none).
 // Lanes of one build instruction that share a hash are chained by ONE ds_wrxchg_rtn: on
@@ -449,10 +449,10 @@ __device__ unsigned long long lzs_prof[16];
 
 constexpr uint32_t kPool      = 512;             // positions hoisted per round
 constexpr uint32_t kLinkN     = 2560;            // 40 x 64 >= 2047 + kPool
-constexpr uint32_t kHead3     = 2048;
+constexpr uint32_t kHead3     = 1024;
 constexpr uint32_t kHead2     = 512;
 constexpr uint32_t kNoLink    = 0xFFFFu;
-constexpr uint32_t kRefillMin = 16;              // idle lanes that justify a refill pass
+constexpr uint32_t kRefillMin = 32;              // idle lanes that justify a refill pass
 
 struct __attribute__((aligned(16))) ChainLds {
     uint32_t ring[kRingWords + 4];               // +16 B mirror of ring[0..15]: reads never wrap
@@ -497,7 +497,7 @@ __device__ __forceinline__ void chain_build(ChainLds &L, uint32_t B, uint32_t n,
     const uint32_t p = B + lane;
     const uint32_t a = (p & kRingMask) >> 2;
     const uint32_t t0 = __builtin_amdgcn_alignbyte(L.ring[a + 1], L.ring[a], p & 3);
-    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 21;           // 11 bits
+    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 22;           // 10 bits
     const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 7) & (kHead2 - 1);  // 9 bits
     uint32_t d3 = kNoLink, d2 = kNoLink;
     // ds_wrxchg_rtn_b32: lanes sharing a slot are served in ascending lane order (see above)
@@ -851,7 +851,7 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
     // offset 1 (full cap), so it is neither inserted nor does it need a link.
     const bool deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
                       p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
-    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 21;
+    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 22;
     const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 7) & (kHead2 - 1);
     const uint32_t slot = wg_slot_base(B) + lane;
     if (wave == 4 || (h3 & 3u) == wave) {
