@@ -765,13 +765,10 @@ struct __attribute__((aligned(16))) BlkLds {
     uint16_t link3[kWgLinkN];
     uint16_t link2[kWgLinkN];
     uint32_t res[kWgPool];                        // off | len << 11 | ext << 15
-    uint16_t jmp[2][kWgPool];                     // pointer-jumping tables (double buffered)
-    uint32_t marks[kWgPool / 32];                 // token starts of the pool
+    uint16_t exitfn[kWgPool];                     // per entry position: where the chain leaves its chunk
     uint32_t bits[kWgBitWords];                   // output bit ring
     uint32_t chunk_bits[8];
     uint32_t nextp;                               // SEARCH work counter
-    uint32_t exit_to;                             // where the token chain leaves the pool
-    uint32_t open_pos;
     uint32_t bcast[8];
 };
 
@@ -1067,63 +1064,67 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         __syncthreads();
         PROF_MARK(5);
 
-        // ---- PARSE + PACK; repeated after each open match that ends inside the pool
+        // ---- PARSE + PACK; repeated after each open match that ends inside the pool.
+        // The greedy chain of token starts is resolved hierarchically.  Inside each 64-position
+        // chunk (two per wave, lane = position) pointer doubling over next[i] = i + bytes
+        // consumed at i runs in registers (ds_bpermute, no barrier) and yields, for EVERY
+        // possible entry position, where the chain leaves the chunk.  One short walk over the
+        // 8 published exit functions then tells each chunk its actual entry, and lane m finds
+        // the m-th token start of its chunk from the kept doubling tables -- so lane order is
+        // token order and the bit offsets are a prefix sum.
         const uint32_t npos = pend - Pb;
         while (c < pend && o.flushed < o.cap) {
             const uint32_t entry = c - Pb;
-            // next[i] for this thread's two positions (chunk `wave` and chunk 4 + `wave`)
-            uint32_t idx[2], nx[2], rr[2];
+            uint32_t rr[2], T[2][6];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t i = 256u * h + 64u * wave + lane;
-                const uint32_t r = L.res[i];
+                const uint32_t gi = 256u * h + 64u * wave + lane;          // pool-relative position
+                const uint32_t r = L.res[gi];
                 const uint32_t len = (r >> 11) & 15u, ext = r >> 15;
-                uint32_t to = i + (len < 2u ? 1u : (len < kTokenMax ? len : kTokenMax + ext));
-                if (len >= kTokenMax && ext == kExtOpen) to = kOpen;
-                idx[h] = i; nx[h] = to; rr[h] = r;
-                L.jmp[0][i] = (uint16_t)to;
-            }
-            if (tid < kWgPool / 32) L.marks[tid] = 0;
-            __syncthreads();
-            if (tid == 0) {
-                L.marks[entry >> 5] = 1u << (entry & 31u);
-                L.exit_to = kOpen;
-                L.open_pos = 0;
-            }
-            __syncthreads();
-            // pointer jumping: after round k every token start within 2^(k+1) tokens of the
-            // entry is marked; jumps that leave the pool (>= npos) or hit an open match are
-            // absorbing and identify where the chain ends
-#pragma unroll 1
-            for (uint32_t k = 0; k < 10; k++) {
-                const uint32_t cur = k & 1u;
+                const uint32_t land = lane + (len < 2u ? 1u : (len < kTokenMax ? len : kTokenMax + ext));
+                // codes: < 64 next start inside the chunk; 0x100|j chain leaves at chunk offset j
+                // (j >= 64, or the end of the pool); 0x200|i open match at chunk offset i
+                uint32_t t = (land < 64u && gi - lane + land < npos) ? land : (0x100u | land);
+                if (len >= kTokenMax && ext == kExtOpen) t = 0x200u | lane;
+                if (gi >= npos) t = 0x100u | lane;
+                rr[h] = r;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t i = idx[h];
-                    const uint32_t j = L.jmp[cur][i];
-                    const bool marked = i < npos && ((L.marks[i >> 5] >> (i & 31u)) & 1u);
-                    if (marked) {
-                        if (j < npos) __hip_atomic_fetch_or(&L.marks[j >> 5], 1u << (j & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else L.exit_to = j;
-                    }
-                    L.jmp[cur ^ 1u][i] = (uint16_t)(j < npos ? L.jmp[cur][j] : j);
+                for (int d = 0; d < 6; d++) {
+                    T[h][d] = t;
+                    const uint32_t via = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((t & 63u) << 2), (int)t);
+                    t = t < 64u ? via : t;
                 }
-                __syncthreads();
+                L.exitfn[gi] = (uint16_t)t;
             }
+            __syncthreads();
+            // walk the exit functions from the entry: at most one step per chunk
+            uint32_t my_entry[2] = {~0u, ~0u};
+            uint32_t pos = entry, chain_end = kOpen, open_at = 0;
+            while (pos < npos) {
+                const uint32_t k = pos >> 6;
+                if (k == wave) my_entry[0] = pos & 63u;
+                if (k == 4u + wave) my_entry[1] = pos & 63u;
+                const uint32_t x = uniform((uint32_t)L.exitfn[pos]);
+                if (x & 0x200u) { open_at = (k << 6) + (x & 63u); pos = ~0u; break; }
+                pos = (k << 6) + (x & 0xFFu);
+            }
+            if (pos != ~0u) chain_end = pos;
             PROF_MARK(3);
-            // the open match (if the chain ends in one) identifies itself
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-                if (idx[h] < npos && nx[h] == kOpen && ((L.marks[idx[h] >> 5] >> (idx[h] & 31u)) & 1u))
-                    L.open_pos = idx[h];
-            // ---- PACK: encode my marked tokens (formats: lzs-compression.c:365-431)
+            // ---- PACK: lane m takes the m-th token of its chunk (formats: lzs-compression.c:365-431)
             uint32_t headv[2], headw[2], tailv[2], tailw[2], incl[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t i = idx[h], r = rr[h];
-                const bool mine = i < npos && nx[h] != kOpen && ((L.marks[i >> 5] >> (i & 31u)) & 1u);
+                const bool entered = my_entry[h] != ~0u;
+                uint32_t node = entered ? my_entry[h] : 0x100u;
+#pragma unroll
+                for (int d = 0; d < 6; d++) {
+                    const uint32_t via = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node & 63u) << 2), (int)T[h][d]);
+                    node = (((lane >> d) & 1u) && node < 64u) ? via : node;
+                }
+                const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node & 63u) << 2), (int)rr[h]);
                 const uint32_t len = (r >> 11) & 15u, ext = r >> 15, off = r & kWindow;
-                uint32_t hv = ring_byte(L.ring, Pb + i) & 0xFFu, hw = 9, tv = 0, tw = 0;      // 0 bbbbbbbb
+                const bool mine = node < 64u && !(len >= kTokenMax && ext == kExtOpen);
+                uint32_t hv = ring_byte(L.ring, Pb + 256u * h + 64u * wave + (node & 63u)) & 0xFFu, hw = 9, tv = 0, tw = 0;
                 if (len >= 2u) {
                     const uint32_t ov = off <= kShortMax ? ((3u << 7) | off) : ((2u << 11) | off);
                     const uint32_t ow = off <= kShortMax ? 9u : 13u;
@@ -1161,8 +1162,6 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                     if (tailw[h]) bits_or(L.bits, kWgBitWords, (at + headw[h]) & 8191u, tailv[h], tailw[h]);
                 }
             }
-            const uint32_t chain_end = L.exit_to;
-            const uint32_t open_at = L.open_pos;
             o.head += total;
             __syncthreads();
             // complete quarters go out, one wave each
