@@ -91,6 +91,16 @@ int lzs_decompress_batch(uint8_t *out, size_t out_stride, size_t out_cap, uint32
                          const uint8_t *in, size_t in_stride, const uint32_t *in_len_each,
                          size_t in_len, size_t nblocks);
 
+/*
+ * Decode a FILE of concatenated streams as the reference's file decompressor does
+ * (c/src/utils/lzs-decompress.c drives the incremental decoder, which after an end marker
+ * drops the pad bits to the byte boundary and carries on: lzs-decompression.c:564-576).
+ * Same arguments, return value and failure mode as lzs_decompress(); decoding stops at the
+ * end of the input or when the output is full.  One wavefront decodes the whole file: use
+ * lzs_decompress_batch() with per-block lengths when they are known.
+ */
+size_t lzs_decompress_concat(uint8_t *out, size_t out_cap, const uint8_t *in, size_t in_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,7 @@ def lib() -> ctypes.CDLL:
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C lzs_compression_amd/csrc`).  There is no CPU fallback.")
         L = ctypes.CDLL(_SO)
-        for name in ("lzs_compress", "lzs_decompress"):
+        for name in ("lzs_compress", "lzs_decompress", "lzs_decompress_concat"):
             f = getattr(L, name)
             f.restype, f.argtypes = _sz, [_vp, _sz, _vp, _sz]
         L.lzs_last_error.restype, L.lzs_last_error.argtypes = ctypes.c_char_p, []
@@ -116,6 +116,12 @@ def compress(data: bytes, out_capacity: Optional[int] = None) -> bytes:
 def decompress(data: bytes, out_capacity: int) -> bytes:
     """lzs_decompress() (reference lzs-decompression.c:156-412)."""
     return _one_shot(lib().lzs_decompress, data, out_capacity)
+
+
+def decompress_concat(data: bytes, out_capacity: int) -> bytes:
+    """A file of streams back to back, decoded as the reference's file tool does
+    (decoder carries on after each end marker: reference lzs-decompression.c:564-576)."""
+    return _one_shot(lib().lzs_decompress_concat, data, out_capacity)
 
 
 # --------------------------------------------------------------- host batches (numpy)

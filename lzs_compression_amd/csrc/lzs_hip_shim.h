@@ -35,6 +35,9 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
 int lzs_hip_launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                               const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                               uint32_t in_len, uint32_t nblocks, void *stream);
+int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                                     const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                                     uint32_t in_len, uint32_t nblocks, void *stream);
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks,
                            void *stream);

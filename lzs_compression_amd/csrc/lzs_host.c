@@ -229,3 +229,8 @@ size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t
 {
     return one_shot("lzs_decompress", lzs_hip_launch_decompress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
+
+size_t lzs_decompress_concat(uint8_t *out, size_t out_cap, const uint8_t *in, size_t in_len)
+{
+    return one_shot("lzs_decompress_concat", lzs_hip_launch_decompress_concat, out, out_cap, in, in_len);
+}

@@ -1263,7 +1263,7 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
                                   uint32_t *__restrict__ out_len,
                                   const uint8_t *__restrict__ in, size_t in_stride,
                                   const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
-                                  uint32_t nblocks)
+                                  uint32_t nblocks, uint32_t concat)
 {
     __shared__ DecLds lds[kWavesPerWG];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1314,6 +1314,16 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
             bits <<= 4; have -= 4;
             copy_len = e;
             if (e != kNibbleMax) extended = false;
+        } else if ((bits >> 63) == 0 && have >= 9) {
+            // a run of literals (:217-233), up to 7 at once: token i of an all-literal run starts
+            // at bit 63 - 9i, so the first set type bit among those tells how long the run is
+            const uint64_t types = bits & 0x8040201008040200ull;
+            uint32_t k = (types ? (uint32_t)__builtin_clzll(types) : 64u) / 9u;
+            k = k < have / 9u ? k : have / 9u;
+            k = k < cap - count ? k : cap - count;
+            if (lane < k) ring8[(count + lane) & kRingMask] = (uint8_t)(bits >> (55u - 9u * lane));
+            count += k;
+            bits <<= 9u * k; have -= 9u * k;
         } else {
             const uint32_t is_match = (uint32_t)(bits >> 63);
             bits <<= 1; have -= 1;
@@ -1331,7 +1341,14 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
                     if (have < 7) break;
                     off = (uint32_t)(bits >> 57);
                     bits <<= 7; have -= 7;
-                    if (off == 0) break;                           // end marker
+                    if (off == 0) {                                // end marker
+                        if (!concat) break;                        // one-shot rule: stop (:255-260)
+                        // file rule (the incremental decoder, :564-576): drop the pad bits up
+                        // to the byte boundary and go on with the next stream
+                        const uint32_t pad = have & 7u;
+                        bits <<= pad; have -= pad;
+                        continue;
+                    }
                 } else {                                           // :272-279
                     if (have < 11) break;
                     off = (uint32_t)(bits >> 53);
@@ -1514,16 +1531,30 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
     return (int)hipGetLastError();
 }
 
-int lzs_hip_launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
-                              const void *d_in, size_t in_stride, const uint32_t *d_in_len,
-                              uint32_t in_len, uint32_t nblocks, void *stream)
+static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                             const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                             uint32_t in_len, uint32_t nblocks, void *stream, uint32_t concat)
 {
     if (nblocks == 0) return 0;
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
     hipLaunchKernelGGL(lzs_decompress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
                        (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
     return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                              const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                              uint32_t in_len, uint32_t nblocks, void *stream)
+{
+    return launch_decompress(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, stream, 0);
+}
+
+int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                                     const void *d_in, size_t in_stride, const uint32_t *d_in_len,
+                                     uint32_t in_len, uint32_t nblocks, void *stream)
+{
+    return launch_decompress(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, stream, 1);
 }
 
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
