@@ -837,17 +837,22 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
 {
     const uint32_t p = B + lane;
     const uint32_t a = (p & kRingMask) >> 2, sh = p & 3;
-    const uint32_t d0 = L.ring[a], d1 = L.ring[a + 1], d2 = L.ring[a + 2], d3 = L.ring[a + 3], d4 = L.ring[a + 4];
+    const uint32_t d0 = L.ring[a], d1 = L.ring[a + 1];
     const uint32_t t0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    const uint32_t t1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    const uint32_t t2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    const uint32_t t3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
     const uint32_t splat = (t0 & 0xFFu) * 0x01010101u;
     // Interior of a run: the same byte before, and 13 equal bytes ahead.  Such a position is
     // dominated by p+1 as a candidate for every later position, and its own search ends at
     // offset 1 (full cap), so it is neither inserted nor does it need a link.
-    const bool deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
-                      p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
+    // Four equal bytes are the cheap necessary condition; the rest is looked at only then.
+    bool deep = false;
+    if (__any(t0 == splat)) {
+        const uint32_t d2 = L.ring[a + 2], d3 = L.ring[a + 3], d4 = L.ring[a + 4];
+        const uint32_t t1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const uint32_t t2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        const uint32_t t3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
+               p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
+    }
     const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 22;
     const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 7) & (kHead2 - 1);
     const uint32_t slot = wg_slot_base(B) + lane;
