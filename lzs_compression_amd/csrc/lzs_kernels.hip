@@ -958,12 +958,14 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
         uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
         len = len < lim ? len : lim;
         // 3-byte chain: first strictly longer match >= 3 wins, the cap ends the walk (:337-345);
-        // 2-byte chain: the first verified candidate is the answer
-        const bool better = three ? (len > best_len && len >= 3u) : (len >= 2u && best_len < 2u);
-        const bool takeit = inwin && better;
+        // 2-byte chain: the first verified candidate is the answer.  Written as thresholds so
+        // that the compiler emits selects, not branches on `three`.
+        const uint32_t beat = three ? (best_len > 2u ? best_len : 2u) : 1u;    // len must exceed this
+        const uint32_t stop_at = three ? lim : 2u;                             // len that ends the walk
+        const bool takeit = inwin && len > beat;
         best_len = takeit ? len : best_len;
         best_off = takeit ? cum2 : best_off;
-        const bool ended = !inwin || (three ? len == lim : len >= 2u);
+        const bool ended = !inwin || len >= stop_at;
         // nothing >= 2 so far and the 3-byte chain is exhausted: restart on the 2-byte chain
         const bool fallback = busy && ended && three && best_len < 2u;
         const bool finish = busy && ended && !fallback;
