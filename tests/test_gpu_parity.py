@@ -254,6 +254,39 @@ def test_single_long_stream_keeps_history_across_64k():
     assert lzs.decompress(got, len(data)) == data
 
 
+def test_multi_megabyte_single_stream():
+    """One 3 MiB stream through the 4-argument call: positions well past 2^16 (16-bit head
+    aliasing would show here) and a mix of the three classes, bit-exact vs the oracle."""
+    parts = [workload.fill("text", 20).tobytes(), workload.fill("lowent", 12).tobytes(),
+             workload.fill("random", 8).tobytes(), workload.fill("text", 8, first_block=100).tobytes()]
+    data = b"".join(parts)[:3 * 1024 * 1024 + 12345]
+    got = lzs.compress(data)
+    assert got == O.compress(data)
+    assert lzs.decompress(got, len(data)) == data
+
+
+@pytest.mark.parametrize("variant", ["chain", "scan"])
+def test_other_kernel_variants_agree(variant):
+    """The A/B variants (LZS_KERNEL=chain|scan) produce the same bytes as the default kernel."""
+    import subprocess, sys, os
+    code = (
+        "import numpy as np, hashlib, lzs_compression_amd as lzs\n"
+        "from lzs_compression_amd import workload\n"
+        "h = hashlib.sha256()\n"
+        "for cls in workload.CLASS_NAMES:\n"
+        "    out, n = lzs.compress_batch(workload.fill(cls, 24))\n"
+        "    for b in range(24): h.update(out[b, :n[b]].tobytes())\n"
+        "print(h.hexdigest())\n")
+    env = dict(os.environ)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env["PYTHONPATH"] = root
+    base = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    env["LZS_KERNEL"] = variant
+    other = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert base.returncode == 0 and other.returncode == 0, (base.stderr, other.stderr)
+    assert base.stdout.strip() == other.stdout.strip() and len(base.stdout.strip()) == 64
+
+
 # ------------------------------------------------------------ BASELINE.json full-size configs
 @pytest.mark.parametrize("cls", workload.CLASS_NAMES)
 def test_full_size_1gib_roundtrip_and_sampled_oracle(cls):
