@@ -1380,7 +1380,9 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
             __builtin_amdgcn_wave_barrier();
             uint32_t v = 0;
             if (lane < m) {
-                const uint32_t k = lane % off;                     // overlap replicates
+                // overlap replicates with period `off`; m <= 15, so only short offsets wrap
+                // (`off` is wave-uniform: the division is skipped for the common long offsets)
+                const uint32_t k = off > 15u ? lane : lane % off;
                 const uint32_t from = count + k;                   // position + off of the source
                 v = from >= off ? ring8[(from - off) & kRingMask] : 0u;   // before out[0] -> 0
             }
