@@ -12,21 +12,28 @@ __global__ void probe(const uint32_t *addr, uint32_t *bad_max, uint32_t *bad_xch
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t *t = tab + wv * 2048;
     for (uint32_t pat = blockIdx.x * 4 + wv; pat < npat; pat += gridDim.x * 4) {
-        const uint32_t a = addr[pat * 64 + lane] & 2047;
-        // expected: nearest lower lane with the same address (+1), else 0
+        const uint32_t raw = addr[pat * 64 + lane];
+        const uint32_t a = raw & 2047;
+        // every other pattern runs under a partial EXEC mask (as the build does: a wave only
+        // inserts the lanes whose buckets it owns)
+        const bool active = (pat & 1u) == 0 || ((raw >> 13) & 3u) != 0;
+        // expected: nearest lower ACTIVE lane with the same address (+1), else 0
         uint32_t expect = 0;
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t al = __shfl((int)a, (int)l, 64);
-            if (l < lane && al == a) expect = l + 1;
+            const int act = __shfl((int)active, (int)l, 64);
+            if (l < lane && al == a && act) expect = l + 1;
         }
         t[a] = 0;
         __builtin_amdgcn_wave_barrier();
-        const uint32_t got = atomicMax(&t[a], lane + 1);
+        uint32_t got = expect;
+        if (active) got = atomicMax(&t[a], lane + 1);
         __builtin_amdgcn_wave_barrier();
         if (got != expect) atomicAdd(bad_max, 1);
         t[a] = 0;
         __builtin_amdgcn_wave_barrier();
-        const uint32_t got2 = atomicExch(&t[a], lane + 1);
+        uint32_t got2 = expect;
+        if (active) got2 = atomicExch(&t[a], lane + 1);
         __builtin_amdgcn_wave_barrier();
         if (got2 != expect) atomicAdd(bad_xchg, 1);
     }
@@ -42,13 +49,14 @@ int main()
         for (uint32_t l = 0; l < 64; l++) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             uint32_t v = (uint32_t)(x >> 20);
+            const uint32_t maskbits = (uint32_t)(x >> 5) & (3u << 13);   // drives the partial EXEC mask
             // few distinct addresses; same-bank strides (x32, x64 dwords); random; runs
             if (mode < 4) v &= (1u << (mode + 1)) - 1;
             else if (mode == 4) v = (v & 7) * 32;
             else if (mode == 5) v = (v & 15) * 64 + ((v >> 8) & 1);
             else if (mode == 6) v &= 2047;
             else v = (l / 5) * 33;
-            h[p * 64 + l] = v;
+            h[p * 64 + l] = (v & 2047u) | maskbits;
         }
     }
     uint32_t *d, *bad;
