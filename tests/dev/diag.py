@@ -3,7 +3,7 @@
 the first divergence in detail; then times a small batch.  Development aid (uses oracle/)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 import torch
 import oracle

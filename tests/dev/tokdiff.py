@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: decode two LZS streams into token lists and show where they first differ."""
 import sys, os
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 
 
