@@ -1331,6 +1331,31 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
             if (lane < k) ring8[(count + lane) & kRingMask] = (uint8_t)(bits >> (55u - 9u * lane));
             count += k;
             bits <<= 9u * k; have -= 9u * k;
+        } else if (have > 32 && (bits >> 63) != 0) {
+            // a match token whose bits are all certainly there (at most 17 + 4 of more than 32):
+            // same decoding as below without the per-field "enough bits left?" tests
+            const uint32_t top = (uint32_t)(bits >> 43);           // 1 s ooooooo[oooo] cccc ...
+            const bool is_short = (top >> 19) & 1u;
+            const uint32_t o = is_short ? (top >> 12) & 0x7Fu : (top >> 8) & 0x7FFu;
+            const uint32_t used = is_short ? 9u : 13u;
+            if (o == 0) {
+                bits <<= used; have -= used;
+                if (is_short) {                                    // end marker (:255-260 / :564-576)
+                    if (!concat) break;
+                    const uint32_t pad = have & 7u;
+                    bits <<= pad; have -= pad;
+                } else {
+                    off = 0;                                       // long offset 0: no copy (:280)
+                }
+                continue;
+            }
+            const uint32_t code = (is_short ? top >> 8 : top >> 4) & 0xFu;
+            const uint32_t len = code < 0xC ? 2 + (code >> 2) : 5 + (code - 0xC);
+            const uint32_t width = code < 0xC ? 2u : 4u;
+            bits <<= used + width; have -= used + width;
+            off = o;
+            if (len == kTokenMax) extended = true;
+            copy_len = len;
         } else {
             const uint32_t is_match = (uint32_t)(bits >> 63);
             bits <<= 1; have -= 1;
