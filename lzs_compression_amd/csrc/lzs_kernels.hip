@@ -1513,7 +1513,7 @@ int lzs_hip_describe(char *buf, size_t cap)
     hipDeviceProp_t p;
     e = hipGetDeviceProperties(&p, dev);
     if (e != hipSuccess) return (int)e;
-    snprintf(buf, cap, "hip device %d: %s (%s), %d CUs, %.0f GiB, LDS/CU %zu KiB; kernels: wave-per-block LZS (gfx950)",
+    snprintf(buf, cap, "hip device %d: %s (%s), %d CUs, %.0f GiB, LDS/CU %zu KiB; kernels: workgroup-per-block LZS compress, wave-per-stream decompress (gfx950)",
              dev, p.name, p.gcnArchName, p.multiProcessorCount,
              (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0),
              (size_t)p.maxSharedMemoryPerMultiProcessor / 1024);
