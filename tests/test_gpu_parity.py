@@ -254,6 +254,33 @@ def test_single_long_stream_keeps_history_across_64k():
     assert lzs.decompress(got, len(data)) == data
 
 
+def test_one_shot_calls_from_many_host_threads():
+    """The reference's calls are re-entrant (no globals: lzs-compression.c:100-124 holds only
+    const tables); ours must stay callable concurrently from many host threads."""
+    import threading
+    rng = np.random.default_rng(9)
+    datas = list(_fuzz_inputs(rng, 48, 20000))
+    want = [O.compress(d) for d in datas]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for i in range(tid, len(datas), 8):
+                    got = lzs.compress(datas[i])
+                    if got != want[i] or lzs.decompress(got, len(datas[i]) + 1) != datas[i]:
+                        errors.append((tid, i))
+        except Exception as e:      # noqa: BLE001 - collected for the assertion below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_multi_megabyte_single_stream():
     """One 3 MiB stream through the 4-argument call: positions well past 2^16 (16-bit head
     aliasing would show here) and a mix of the three classes, bit-exact vs the oracle."""
