@@ -7,8 +7,10 @@
  * Public surface: include/lzs/lzs.h (the reference's one-shot calls,
  * c/src/liblzs/lzs.h:218,229) and include/lzs/lzs_batch.h (additive batch calls).
  */
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "lzs/lzs.h"
@@ -109,10 +111,69 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
     return e ? hip_fail(e, "lzs_compact_device") : LZS_OK;
 }
 
+/* ------------------------------------------------- per-thread staging (host batches) */
+/* Each host thread keeps one HIP stream and four grow-only device buffers for the host-buffer
+ * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
+ * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
+enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_COUNT };
+#define KEEP_MAX ((size_t)256 << 20)
+
+typedef struct {
+    void  *stream;
+    void  *buf[BUF_COUNT];
+    size_t cap[BUF_COUNT];
+} staging_t;
+
+static pthread_key_t  staging_key;
+static pthread_once_t staging_once = PTHREAD_ONCE_INIT;
+
+static void staging_destroy(void *p)
+{
+    staging_t *st = (staging_t *)p;
+    if (!st) return;
+    for (int i = 0; i < BUF_COUNT; i++)
+        if (st->buf[i]) lzs_hip_free(st->buf[i]);
+    if (st->stream) lzs_hip_stream_destroy(st->stream);
+    free(st);
+}
+
+static void staging_make_key(void) { pthread_key_create(&staging_key, staging_destroy); }
+
+static staging_t *staging_get(void)
+{
+    pthread_once(&staging_once, staging_make_key);
+    staging_t *st = (staging_t *)pthread_getspecific(staging_key);
+    if (!st) {
+        st = (staging_t *)calloc(1, sizeof(*st));
+        if (st) pthread_setspecific(staging_key, st);
+    }
+    return st;
+}
+
+/* 0 on success, else a hipError_t */
+static int staging_reserve(staging_t *st, int which, size_t bytes, void **out)
+{
+    if (st->cap[which] < bytes) {
+        if (st->buf[which]) { lzs_hip_free(st->buf[which]); st->buf[which] = NULL; st->cap[which] = 0; }
+        size_t want = (bytes + 65535u) & ~(size_t)65535u;
+        int e = lzs_hip_malloc(&st->buf[which], want);
+        if (e) return e;
+        st->cap[which] = want;
+    }
+    *out = st->buf[which];
+    return 0;
+}
+
+static void staging_trim(staging_t *st)
+{
+    for (int i = 0; i < BUF_COUNT; i++)
+        if (st->cap[i] > KEEP_MAX) { lzs_hip_free(st->buf[i]); st->buf[i] = NULL; st->cap[i] = 0; }
+}
+
 /* -------------------------------------------------------------------- host batches */
-/* Stage host buffers through device memory owned by this call.  Blocks are packed on
- * the device with 16-byte-aligned strides so the kernels take their aligned paths,
- * whatever the caller's strides are. */
+/* Stage host buffers through this thread's device memory.  Blocks are packed on the device
+ * with 16-byte-aligned strides so the kernels take their aligned paths, whatever the
+ * caller's strides are. */
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t out_stride,
@@ -137,13 +198,16 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     void *stream = NULL, *d_in = NULL, *d_out = NULL, *d_len = NULL, *d_in_len = NULL;
     int e = 0;
     rc = LZS_OK;
+    staging_t *st = staging_get();
+    if (!st) return fail(LZS_E_NOMEM, "%s: out of host memory", who);
 
 #define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto done; } } while (0)
-    HIP_TRY(lzs_hip_stream_create(&stream), "hipStreamCreate");
-    e = lzs_hip_malloc(&d_in, d_in_stride * nblocks);
-    if (!e) e = lzs_hip_malloc(&d_out, d_out_stride * nblocks);
-    if (!e) e = lzs_hip_malloc(&d_len, sizeof(uint32_t) * nblocks);
-    if (!e && in_len_each) e = lzs_hip_malloc(&d_in_len, sizeof(uint32_t) * nblocks);
+    if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
+    stream = st->stream;
+    e = staging_reserve(st, BUF_IN, d_in_stride * nblocks, &d_in);
+    if (!e) e = staging_reserve(st, BUF_OUT, d_out_stride * nblocks, &d_out);
+    if (!e) e = staging_reserve(st, BUF_LEN, sizeof(uint32_t) * nblocks, &d_len);
+    if (!e && in_len_each) e = staging_reserve(st, BUF_INLEN, sizeof(uint32_t) * nblocks, &d_in_len);
     if (e) { rc = fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
 
     if (in_stride == d_in_stride && !in_len_each) {
@@ -170,11 +234,8 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
 #undef HIP_TRY
 
 done:
-    if (d_in) lzs_hip_free(d_in);
-    if (d_out) lzs_hip_free(d_out);
-    if (d_len) lzs_hip_free(d_len);
-    if (d_in_len) lzs_hip_free(d_in_len);
-    if (stream) lzs_hip_stream_destroy(stream);
+    if (rc != LZS_OK && stream) lzs_hip_stream_sync(stream);   /* nothing of ours may still be in flight */
+    staging_trim(st);
     return rc;
 }
 
