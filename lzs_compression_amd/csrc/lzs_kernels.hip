@@ -774,10 +774,13 @@ struct __attribute__((aligned(16))) BlkLds {
 
 __device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) % 40u) * 64u; }
 
+// Equal leading bytes of two 12-byte strings given the XOR of their little-endian words;
+// 12 or more (a large number) when all are equal -- callers clamp to their own limit.
 __device__ __forceinline__ uint32_t lcp12(uint32_t x0, uint32_t x1, uint32_t x2)
 {
-    const uint32_t e0 = eq_bytes(x0), e1 = eq_bytes(x1), e2 = eq_bytes(x2);
-    return e0 + (e0 == 4 ? e1 + (e1 == 4 ? e2 : 0u) : 0u);
+    const uint32_t tail = x1 ? x1 : x2, tail_at = x1 ? 4u : 8u;
+    const uint32_t word = x0 ? x0 : tail, at = x0 ? 0u : tail_at;     // first word that differs
+    return at + (((uint32_t)__builtin_ffs((int)word) - 1u) >> 3);      // word == 0 -> huge
 }
 
 // OR `width` (1..32) bits of `value`, MSB first, at bit offset `at` of a ring of `words` words.
@@ -984,6 +987,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
                     ringm_read12(L.ring, p + total, a0, a1, a2);
                     ringm_read12(L.ring, p + total - best_off, b0, b1, b2);
                     uint32_t e = lcp12(a0 ^ b0, a1 ^ b1, a2 ^ b2);
+                    e = e < 12u ? e : 12u;
                     e = e < room - total ? e : room - total;
                     total += e;
                     if (e < 12u || total >= room) break;
