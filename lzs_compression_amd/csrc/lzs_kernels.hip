@@ -780,7 +780,9 @@ __device__ __forceinline__ uint32_t lcp12(uint32_t x0, uint32_t x1, uint32_t x2)
 {
     const uint32_t tail = x1 ? x1 : x2, tail_at = x1 ? 4u : 8u;
     const uint32_t word = x0 ? x0 : tail, at = x0 ? 0u : tail_at;     // first word that differs
-    return at + (((uint32_t)__builtin_ffs((int)word) - 1u) >> 3);      // word == 0 -> huge
+    uint32_t low;                                                      // v_ffbl_b32: -1 for 0
+    asm("v_ffbl_b32 %0, %1" : "=v"(low) : "v"(word));
+    return at + (low >> 3);                                            // word == 0 -> huge
 }
 
 // OR `width` (1..32) bits of `value`, MSB first, at bit offset `at` of a ring of `words` words.
@@ -891,6 +893,10 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
     bool busy = false, three = false, pool_done = false;
     uint32_t p = Pb, t0 = 0, t1 = 0, t2 = 0, lim = 0, reach = 0, myslot = slot0, first2 = kNoLink;
     uint32_t cum = 0, dist = kNoLink, best_len = 0, best_off = 0;
+    // per walk, kept in registers instead of being re-derived each step: the length a match
+    // must exceed, the length that ends the walk, and which link array is being followed
+    uint32_t beat = 1, stop_at = 2;
+    const uint16_t *links = L.link2;
     for (;;) {
         const uint64_t idle = __ballot(!busy);
         const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
@@ -943,6 +949,11 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
             cum = take ? 0u : cum;
             best_len = take ? (seeded ? len1 : 0u) : best_len;
             best_off = take ? (seeded ? 1u : 0u) : best_off;
+            // 3-byte chain: a match must beat max(best, 2) and the cap ends the walk (:337-345);
+            // 2-byte chain: the first verified candidate (>= 2) is the answer
+            beat = take ? (walk3 ? (seeded ? len1 : 2u) : 1u) : beat;
+            stop_at = take ? (walk3 ? nlim : 2u) : stop_at;
+            links = take ? (walk3 ? L.link3 : L.link2) : links;
             busy = busy || (take && !instant);
         }
         if (__ballot(busy) == 0ull) {
@@ -957,17 +968,13 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
         ringm_read12(L.ring, p - (inwin ? cum2 : 0u), w0, w1, w2);
         int32_t at = (int32_t)myslot - (int32_t)(inwin ? cum2 : 0u);
         at = at < 0 ? at + (int32_t)kWgLinkN : at;
-        const uint32_t nd = three ? L.link3[at] : L.link2[at];
+        const uint32_t nd = links[at];
         uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
         len = len < lim ? len : lim;
-        // 3-byte chain: first strictly longer match >= 3 wins, the cap ends the walk (:337-345);
-        // 2-byte chain: the first verified candidate is the answer.  Written as thresholds so
-        // that the compiler emits selects, not branches on `three`.
-        const uint32_t beat = three ? (best_len > 2u ? best_len : 2u) : 1u;    // len must exceed this
-        const uint32_t stop_at = three ? lim : 2u;                             // len that ends the walk
         const bool takeit = inwin && len > beat;
         best_len = takeit ? len : best_len;
         best_off = takeit ? cum2 : best_off;
+        beat = takeit ? len : beat;
         const bool ended = !inwin || len >= stop_at;
         // nothing >= 2 so far and the 3-byte chain is exhausted: restart on the 2-byte chain
         const bool fallback = busy && ended && three && best_len < 2u;
@@ -975,6 +982,9 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
         cum = fallback ? 0u : cum2;
         dist = fallback ? first2 : nd;
         three = three && !fallback;
+        beat = fallback ? 1u : beat;
+        stop_at = fallback ? 2u : stop_at;
+        links = fallback ? L.link2 : links;
         if (finish) {
             // a match that fills the search cap may run on: measure it (up to kExtMax more
             // than the 8 of the first code) so the token is complete (:417-431)
