@@ -850,7 +850,7 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
     // offset 1 (full cap), so it is neither inserted nor does it need a link.
     // Four equal bytes are the cheap necessary condition; the rest is looked at only then.
     bool deep = false;
-    if (__any(t0 == splat)) {
+    if ((__builtin_amdgcn_ballot_w64(t0 == splat) != 0ull)) {
         const uint32_t d2 = L.ring[a + 2], d3 = L.ring[a + 3], d4 = L.ring[a + 4];
         const uint32_t t1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
         const uint32_t t2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
@@ -898,7 +898,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
     uint32_t beat = 1, stop_at = 2;
     const uint16_t *links = L.link2;
     for (;;) {
-        const uint64_t idle = __ballot(!busy);
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(!busy);
         const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
         if (!pool_done && (nidle >= kRefillMin || nidle == 64u)) {
             uint32_t basep = 0;
@@ -910,7 +910,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
             const uint32_t np = basep + rank;
             const bool take = !busy && np < pend;
             PROF_COUNT(9, 1);
-            PROF_COUNT(10, __builtin_popcountll(__ballot(take)));
+            PROF_COUNT(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(take)));
             const uint32_t pp = take ? np : p;                          // every lane reads in range
             uint32_t n0, n1, n2;
             ringm_read12(L.ring, pp, n0, n1, n2);
@@ -924,7 +924,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
             // the 12-byte form is computed only when some lane needs it.
             const bool maybe1 = take && pp >= 1u && ((n0 ^ ((n0 << 8) | before)) & 0xFFFFu) == 0;
             uint32_t len1 = 0;
-            if (__any(maybe1)) {
+            if ((__builtin_amdgcn_ballot_w64(maybe1) != 0ull)) {
                 len1 = lcp12(n0 ^ ((n0 << 8) | before), n1 ^ ((n1 << 8) | (n0 >> 24)), n2 ^ ((n2 << 8) | (n1 >> 24)));
                 len1 = len1 < nlim ? len1 : nlim;
             }
@@ -956,12 +956,12 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
             links = take ? (walk3 ? L.link3 : L.link2) : links;
             busy = busy || (take && !instant);
         }
-        if (__ballot(busy) == 0ull) {
+        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) {
             if (pool_done) break;
             continue;
         }
         PROF_COUNT(11, 1);
-        PROF_COUNT(8 + 4, __builtin_popcountll(__ballot(busy)));
+        PROF_COUNT(8 + 4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy)));
         const uint32_t cum2 = cum + dist;
         const bool inwin = busy && cum2 <= reach;
         uint32_t w0, w1, w2;
@@ -1220,7 +1220,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                         const uint32_t span = rem < 60u ? rem : 60u;
                         const bool differs = lane < span &&
                                              ring_byte(L.ring, c + lane) != ring_byte(L.ring, c + lane - off);
-                        const uint64_t stopmask = __ballot(differs) | (1ull << span);
+                        const uint64_t stopmask = __builtin_amdgcn_ballot_w64(differs) | (1ull << span);
                         const uint32_t m = uniform((uint32_t)__builtin_ctzll(stopmask));   // equal bytes <= span
                         c += m;
                         const uint32_t full = m / kNibbleMax;
