@@ -911,50 +911,48 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
             const bool take = !busy && np < pend;
             PROF_COUNT(9, 1);
             PROF_COUNT(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(take)));
-            const uint32_t pp = take ? np : p;                          // every lane reads in range
-            uint32_t n0, n1, n2;
-            ringm_read12(L.ring, pp, n0, n1, n2);
-            const uint32_t before = ring_byte(L.ring, pp - 1u);
-            uint32_t sl = slot0 + (pp - Pb);
-            sl = sl >= kWgLinkN ? sl - kWgLinkN : sl;
-            const uint32_t l3 = L.link3[sl], l2 = L.link2[sl];
-            const uint32_t nlim = n - pp < kSearchCap ? n - pp : kSearchCap;
-            // offset 1 first: common prefix of the text with itself shifted by one byte.  It
-            // can only reach 2 if the byte before equals the next two, which is rare in text:
-            // the 12-byte form is computed only when some lane needs it.
-            const bool maybe1 = take && pp >= 1u && ((n0 ^ ((n0 << 8) | before)) & 0xFFFFu) == 0;
-            uint32_t len1 = 0;
-            if ((__builtin_amdgcn_ballot_w64(maybe1) != 0ull)) {
-                len1 = lcp12(n0 ^ ((n0 << 8) | before), n1 ^ ((n1 << 8) | (n0 >> 24)), n2 ^ ((n2 << 8) | (n1 >> 24)));
-                len1 = len1 < nlim ? len1 : nlim;
+            if (take) {                                                  // exec-masked: direct writes, no selects
+                p = np;
+                ringm_read12(L.ring, p, t0, t1, t2);
+                const uint32_t before = ring_byte(L.ring, p - 1u);
+                uint32_t sl = slot0 + (p - Pb);
+                sl = sl >= kWgLinkN ? sl - kWgLinkN : sl;
+                myslot = sl;
+                const uint32_t l3 = L.link3[sl], l2 = L.link2[sl];
+                lim = n - p < kSearchCap ? n - p : kSearchCap;
+                // offset 1 first: common prefix of the text with itself shifted by one byte.  It
+                // can only reach 2 if the byte before equals the next two, which is rare in text:
+                // the 12-byte form is computed only when some lane needs it.
+                const bool maybe1 = p >= 1u && ((t0 ^ ((t0 << 8) | before)) & 0xFFFFu) == 0;
+                uint32_t len1 = 0;
+                if (__builtin_amdgcn_ballot_w64(maybe1) != 0ull) {
+                    len1 = lcp12(t0 ^ ((t0 << 8) | before), t1 ^ ((t1 << 8) | (t0 >> 24)), t2 ^ ((t2 << 8) | (t1 >> 24)));
+                    len1 = len1 < lim ? len1 : lim;
+                }
+                const bool seeded = maybe1 && len1 >= 2u;
+                const bool capped = seeded && len1 == lim;               // nothing nearer or longer exists
+                reach = p < kWindow ? p : kWindow;
+                // chains that are empty inside the window are skipped here, not discovered by a step
+                const bool walk3 = lim >= 3u && !capped && l3 <= reach;
+                const bool walk2 = lim >= 2u && !capped && !seeded && l2 <= reach;
+                // no candidate anywhere: a literal, or the offset-1 match as it stands (a match that
+                // fills the 12-byte cap still goes through a step so that its extension is measured)
+                const bool instant = !walk3 && !walk2 && !(seeded && len1 == kSearchCap);
+                if (instant)
+                    L.res[p - Pb] = seeded ? (1u | (len1 << 11) | ((len1 >= kTokenMax ? len1 - kTokenMax : 0u) << 15)) : 0u;
+                three = walk3;
+                first2 = walk2 ? l2 : kNoLink;
+                dist = walk3 ? l3 : first2;
+                cum = 0u;
+                best_len = seeded ? len1 : 0u;
+                best_off = seeded ? 1u : 0u;
+                // 3-byte chain: a match must beat max(best, 2) and the cap ends the walk (:337-345);
+                // 2-byte chain: the first verified candidate (>= 2) is the answer
+                beat = walk3 ? (seeded ? len1 : 2u) : 1u;
+                stop_at = walk3 ? lim : 2u;
+                links = walk3 ? L.link3 : L.link2;
+                busy = !instant;
             }
-            const bool seeded = maybe1 && len1 >= 2u;
-            const bool capped = seeded && len1 == nlim;                 // nothing nearer or longer exists
-            const uint32_t nreach = pp < kWindow ? pp : kWindow;
-            // chains that are empty inside the window are skipped here, not discovered by a step
-            const bool walk3 = nlim >= 3u && !capped && l3 <= nreach;
-            const bool walk2 = nlim >= 2u && !capped && !seeded && l2 <= nreach;
-            // no candidate anywhere: a literal, or the offset-1 match as it stands (a match that
-            // fills the 12-byte cap still goes through a step so that its extension is measured)
-            const bool instant = take && !walk3 && !walk2 && !(seeded && len1 == kSearchCap);
-            if (instant)
-                L.res[pp - Pb] = seeded ? (1u | (len1 << 11) | ((len1 >= kTokenMax ? len1 - kTokenMax : 0u) << 15)) : 0u;
-            p = pp; myslot = sl;
-            t0 = take ? n0 : t0; t1 = take ? n1 : t1; t2 = take ? n2 : t2;
-            lim = take ? nlim : lim;
-            reach = take ? nreach : reach;
-            three = take ? walk3 : three;
-            first2 = take ? (walk2 ? l2 : kNoLink) : first2;
-            dist = take ? (walk3 ? l3 : (walk2 ? l2 : kNoLink)) : dist;
-            cum = take ? 0u : cum;
-            best_len = take ? (seeded ? len1 : 0u) : best_len;
-            best_off = take ? (seeded ? 1u : 0u) : best_off;
-            // 3-byte chain: a match must beat max(best, 2) and the cap ends the walk (:337-345);
-            // 2-byte chain: the first verified candidate (>= 2) is the answer
-            beat = take ? (walk3 ? (seeded ? len1 : 2u) : 1u) : beat;
-            stop_at = take ? (walk3 ? nlim : 2u) : stop_at;
-            links = take ? (walk3 ? L.link3 : L.link2) : links;
-            busy = busy || (take && !instant);
         }
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) {
             if (pool_done) break;
