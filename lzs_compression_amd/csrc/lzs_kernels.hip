@@ -752,7 +752,8 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kWgThreads  = 256;
 constexpr uint32_t kWgPool     = 512;
-constexpr uint32_t kWgLinkN    = 2560;            // 40 x 64 >= 2047 + kWgPool
+constexpr uint32_t kWgLinkN    = 3072;            // 48 x 64 >= 2047 + 2 * kWgPool: the pool in SEARCH and the one before
+constexpr uint32_t kWgResN     = 2 * kWgPool;     // results of two consecutive pools, by position & (kWgResN - 1)
 constexpr uint32_t kWgBitWords = 256;             // 8192-bit ring, quarters of 2048 bits
 constexpr uint32_t kOpen       = 1023;            // jump code of an open match
 constexpr uint32_t kExtOpen    = 63;              // extension code of an open match
@@ -764,7 +765,7 @@ struct __attribute__((aligned(16))) BlkLds {
     uint32_t head2[kHead2];
     uint16_t link3[kWgLinkN];
     uint16_t link2[kWgLinkN];
-    uint32_t res[kWgPool];                        // off | len << 11 | ext << 15
+    uint32_t res[kWgResN];                        // off | len << 11 | ext << 15
     uint16_t exitfn[kWgPool];                     // per entry position: where the chain leaves its chunk
     uint32_t bits[kWgBitWords];                   // output bit ring
     uint32_t chunk_bits[8];
@@ -772,7 +773,7 @@ struct __attribute__((aligned(16))) BlkLds {
     uint32_t bcast[8];
 };
 
-__device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) % 40u) * 64u; }
+__device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) % (kWgLinkN / 64u)) * 64u; }
 
 // Equal leading bytes of two 12-byte strings given the XOR of their little-endian words;
 // 12 or more (a large number) when all are equal -- callers clamp to their own limit.
@@ -879,7 +880,23 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
     }
 }
 
-// SEARCH: every wave pulls positions of [.., pend) from L.nextp until the pool is empty.
+// One lane's SEARCH state.  It lives in registers across pools: a walk that is still going when
+// its wave runs out of fresh positions is carried into the SEARCH of the next pool.
+struct Walk {
+    bool busy, three;
+    uint32_t p, t0, t1, t2, lim, reach, myslot, first2;
+    uint32_t cum, dist, best_len, best_off;
+    // per walk, kept instead of being re-derived each step: the length a match must exceed,
+    // the length that ends the walk, and which link array is being followed
+    uint32_t beat, stop_at;
+    const uint16_t *links;
+};
+
+// SEARCH: every wave pulls positions of [Pb, pend) from L.nextp.  A wave leaves when the pool has
+// no fresh position left and none of its lanes still walks for a position before Pb (those belong
+// to the pool that is parsed next); walks for positions of this pool may be left unfinished.
+// The longest walk of a pool (about 30 steps in text, against 5.5 on average) then no longer
+// holds up 255 other lanes at the end of every pool.
 #ifdef LZS_PROFILE
 #define SEARCH_PROF_PARAMS , unsigned long long *prof_acc
 #define SEARCH_PROF_ARGS , prof_acc
@@ -887,16 +904,15 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
 #define SEARCH_PROF_PARAMS
 #define SEARCH_PROF_ARGS
 #endif
-__device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend, uint32_t n, uint32_t lane SEARCH_PROF_PARAMS)
+__device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint32_t pend, uint32_t n, uint32_t lane SEARCH_PROF_PARAMS)
 {
     const uint32_t slot0 = wg_slot_base(Pb);
-    bool busy = false, three = false, pool_done = false;
-    uint32_t p = Pb, t0 = 0, t1 = 0, t2 = 0, lim = 0, reach = 0, myslot = slot0, first2 = kNoLink;
-    uint32_t cum = 0, dist = kNoLink, best_len = 0, best_off = 0;
-    // per walk, kept in registers instead of being re-derived each step: the length a match
-    // must exceed, the length that ends the walk, and which link array is being followed
-    uint32_t beat = 1, stop_at = 2;
-    const uint16_t *links = L.link2;
+    bool pool_done = false;
+    bool busy = W.busy, three = W.three;
+    uint32_t p = W.p, t0 = W.t0, t1 = W.t1, t2 = W.t2, lim = W.lim, reach = W.reach, myslot = W.myslot, first2 = W.first2;
+    uint32_t cum = W.cum, dist = W.dist, best_len = W.best_len, best_off = W.best_off;
+    uint32_t beat = W.beat, stop_at = W.stop_at;
+    const uint16_t *links = W.links;
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!busy);
         const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
@@ -939,7 +955,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
                 // fills the 12-byte cap still goes through a step so that its extension is measured)
                 const bool instant = !walk3 && !walk2 && !(seeded && len1 == kSearchCap);
                 if (instant)
-                    L.res[p - Pb] = seeded ? (1u | (len1 << 11) | ((len1 >= kTokenMax ? len1 - kTokenMax : 0u) << 15)) : 0u;
+                    L.res[p & (kWgResN - 1)] = seeded ? (1u | (len1 << 11) | ((len1 >= kTokenMax ? len1 - kTokenMax : 0u) << 15)) : 0u;
                 three = walk3;
                 first2 = walk2 ? l2 : kNoLink;
                 dist = walk3 ? l3 : first2;
@@ -954,10 +970,8 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
                 busy = !instant;
             }
         }
-        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) {
-            if (pool_done) break;
-            continue;
-        }
+        if (pool_done && __builtin_amdgcn_ballot_w64(busy && p < Pb) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) continue;
         PROF_COUNT(11, 1);
         PROF_COUNT(8 + 4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy)));
         const uint32_t cum2 = cum + dist;
@@ -1003,10 +1017,14 @@ __device__ __forceinline__ void wg_search(BlkLds &L, uint32_t Pb, uint32_t pend,
                 ext = total - kTokenMax;
             }
             const uint32_t code = ext > kExtMax ? kExtOpen : ext;
-            L.res[p - Pb] = best_off | (best_len << 11) | (code << 15);
+            L.res[p & (kWgResN - 1)] = best_off | (best_len << 11) | (code << 15);
         }
         busy = busy && !finish;
     }
+    W.busy = busy; W.three = three;
+    W.p = p; W.t0 = t0; W.t1 = t1; W.t2 = t2; W.lim = lim; W.reach = reach; W.myslot = myslot; W.first2 = first2;
+    W.cum = cum; W.dist = dist; W.best_len = best_len; W.best_off = best_off;
+    W.beat = beat; W.stop_at = stop_at; W.links = links;
 }
 
 __global__ __launch_bounds__(kWgThreads)
@@ -1044,44 +1062,66 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     uint32_t next = 0;       // next batch of 64 positions to build
     PROF_DECL;
 
-    while (c < n && o.flushed < o.cap) {
-        PROF_MARK(4);
-        // ---- REFILL (256 threads x 4 B per KiB) for the batches up to the end of the pool
-        uint32_t Pb = next;
-        while (Pb + 64 <= c) Pb += 64;                        // batches wholly behind c: built, not searched
-        const uint32_t nup = (n + 63u) & ~63u;
-        const uint32_t Pe = Pb + kWgPool < nup ? Pb + kWgPool : nup;
-        const uint32_t need = (Pe > c ? Pe : c) + 96;
-        while (loaded < n && loaded < need) {
-            const uint32_t p = loaded + 4 * tid;
-            uint32_t v = 0;
-            if (p + 4 <= n && src4) {
-                v = *reinterpret_cast<const uint32_t *>(src + p);
-            } else {
-                for (uint32_t k = 0; k < 4; k++)
-                    if (p + k < n) v |= (uint32_t)src[p + k] << (8 * k);
-            }
-            const uint32_t at = (p & kRingMask) >> 2;
-            L.ring[at] = v;
-            if (at < 4) L.ring[kRingWords + at] = v;
-            loaded += kTile;
-        }
-        __syncthreads();
-        PROF_MARK(0);
+    // The pools are pipelined: while pool k is in SEARCH, pool k-1 (searched in the round before,
+    // except for the walks carried over, which end in this round's SEARCH) waits for PARSE + PACK.
+    Walk W;
+    W.busy = false; W.three = false;
+    W.p = 0; W.t0 = W.t1 = W.t2 = 0; W.lim = 0; W.reach = 0; W.myslot = 0; W.first2 = kNoLink;
+    W.cum = 0; W.dist = kNoLink; W.best_len = 0; W.best_off = 0; W.beat = 1; W.stop_at = 2; W.links = L.link2;
+    bool pending = false;                    // a searched pool waits for PARSE
+    uint32_t Pb = 0, pend = 0;               // that pool
+    const uint32_t nup = (n + 63u) & ~63u;
 
-        // ---- BUILD [next, Pe): every wave walks all batches, inserting into its own buckets
-        for (uint32_t B = next; B < Pe; B += 64) wg_build64(L, B, n, lane, wave);
-        next = Pe;
-        const uint32_t pend = Pe < n ? Pe : n;
-        if (tid == 0) L.nextp = c > Pb ? c : Pb;
+    for (;;) {
+        if (o.flushed >= o.cap) break;
+        if (!pending && (c >= n || next >= nup)) break;
+        PROF_MARK(4);
+        // ---- the next pool [Sb, Se): REFILL (128 threads x 4 B per half KiB) and BUILD
+        const bool fresh = next < nup;
+        uint32_t Sb = next;
+        if (!pending) while (Sb + 64 <= c) Sb += 64;          // batches wholly behind c: built, not searched
+        const uint32_t Se = fresh ? (Sb + kWgPool < nup ? Sb + kWgPool : nup) : Sb;
+        if (fresh) {
+            // Not further ahead than needed: the walks carried over still read 2047 bytes
+            // back from the pool before, and the ring holds 4096.
+            const uint32_t need = (Se > c ? Se : c) + 96;
+            while (loaded < n && loaded < need) {
+                const uint32_t p = loaded + 4 * tid;
+                if (tid < 128) {
+                    uint32_t v = 0;
+                    if (p + 4 <= n && src4) {
+                        v = *reinterpret_cast<const uint32_t *>(src + p);
+                    } else {
+                        for (uint32_t k = 0; k < 4; k++)
+                            if (p + k < n) v |= (uint32_t)src[p + k] << (8 * k);
+                    }
+                    const uint32_t at = (p & kRingMask) >> 2;
+                    L.ring[at] = v;
+                    if (at < 4) L.ring[kRingWords + at] = v;
+                }
+                loaded += kTile / 2;
+            }
+            __syncthreads();
+            PROF_MARK(0);
+            // every wave walks all batches, inserting into its own buckets
+            for (uint32_t B = next; B < Se; B += 64) wg_build64(L, B, n, lane, wave);
+            next = Se;
+        }
+        const uint32_t send = Se < n ? Se : n;
+        if (tid == 0) L.nextp = (!pending && c > Sb) ? c : Sb;
         __syncthreads();
         PROF_MARK(1);
 
-        // ---- SEARCH
-        wg_search(L, Pb, pend, n, lane SEARCH_PROF_ARGS);
+        // ---- SEARCH the new pool; ends every walk for the pending one
+        wg_search(L, W, Sb, send, n, lane SEARCH_PROF_ARGS);
         PROF_MARK(2);
         __syncthreads();
         PROF_MARK(5);
+
+        if (!pending) {                                        // nothing to parse yet
+            Pb = Sb; pend = send; pending = fresh;
+            continue;
+        }
 
         // ---- PARSE + PACK; repeated after each open match that ends inside the pool.
         // The greedy chain of token starts is resolved hierarchically.  Inside each 64-position
@@ -1098,7 +1138,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t gi = 256u * h + 64u * wave + lane;          // pool-relative position
-                const uint32_t r = L.res[gi];
+                const uint32_t r = L.res[(Pb + gi) & (kWgResN - 1)];
                 const uint32_t len = (r >> 11) & 15u, ext = r >> 15;
                 const uint32_t land = lane + (len < 2u ? 1u : (len < kTokenMax ? len : kTokenMax + ext));
                 // codes: < 64 next start inside the chunk; 0x100|j chain leaves at chunk offset j
@@ -1197,7 +1237,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             } else {
                 // ---- open match at Pb + open_at: wave 0 finishes it alone (:417-431)
                 if (wave == 0) {
-                    const uint32_t off = L.res[open_at] & kWindow;
+                    const uint32_t off = L.res[(Pb + open_at) & (kWgResN - 1)] & kWindow;
                     if (lane == 0) {
                         if (off <= kShortMax) bits_or(L.bits, kWgBitWords, wg_bit_at(o), (((3u << 7) | off) << 4) | 0xFu, 13);
                         else                  bits_or(L.bits, kWgBitWords, wg_bit_at(o), (((2u << 11) | off) << 4) | 0xFu, 17);
@@ -1244,6 +1284,9 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             }
         }
         PROF_COUNT(13, 1);
+        // the pool just searched is parsed next, unless an open match ran past all of it
+        Pb = Sb; pend = send; pending = fresh;
+        if (pending && c >= pend) { pending = false; W.busy = false; }
     }
     if (wave == 0) { PROF_DONE; }
 
