@@ -423,8 +423,8 @@ __device__ __forceinline__ void br_finish(BitRing &e, uint32_t *words, uint32_t 
 // ---------------------------------------------------------------------------------
 #ifdef LZS_PROFILE
 // Diagnostic build only (tools/probes/prof_compress): per-phase cycle sums over all waves.
-__device__ unsigned long long lzs_prof[16];
-#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
+__device__ unsigned long long lzs_prof[24];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
 #define PROF_MARK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; } while (0)
 #define PROF_COUNT(i, v) do { prof_acc[i] += (v); } while (0)
 #define PROF_T0 unsigned long long prof_u = __builtin_readcyclecounter()
@@ -433,7 +433,9 @@ __device__ unsigned long long lzs_prof[16];
 #define PROF_T1B(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_v; } while (0)
 #define PROF_T0C unsigned long long prof_w = __builtin_readcyclecounter()
 #define PROF_T1C(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_w; } while (0)
-#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 16; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
+#define PROF_STAMP0 unsigned long long prof_s = __builtin_readcyclecounter()
+#define PROF_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_s; prof_s = t_; } while (0)
+#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 24; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
@@ -444,13 +446,21 @@ __device__ unsigned long long lzs_prof[16];
 #define PROF_T1B(i)
 #define PROF_T0C
 #define PROF_T1C(i)
+#define PROF_STAMP0
+#define PROF_STAMP(i)
 #define PROF_DONE
 #endif
 
 constexpr uint32_t kPool      = 512;             // positions hoisted per round
 constexpr uint32_t kLinkN     = 2560;            // 40 x 64 >= 2047 + kPool
-constexpr uint32_t kHead3     = 1024;
-constexpr uint32_t kHead2     = 1024;
+#ifndef LZS_HEAD3_BITS
+#define LZS_HEAD3_BITS 10
+#endif
+#ifndef LZS_HEAD2_BITS
+#define LZS_HEAD2_BITS 10
+#endif
+constexpr uint32_t kHead3     = 1u << LZS_HEAD3_BITS;
+constexpr uint32_t kHead2     = 1u << LZS_HEAD2_BITS;
 constexpr uint32_t kNoLink    = 0xFFFFu;
 constexpr uint32_t kRefillMin = 32;              // idle lanes that justify a refill pass
 
@@ -497,7 +507,7 @@ __device__ __forceinline__ void chain_build(ChainLds &L, uint32_t B, uint32_t n,
     const uint32_t p = B + lane;
     const uint32_t a = (p & kRingMask) >> 2;
     const uint32_t t0 = __builtin_amdgcn_alignbyte(L.ring[a + 1], L.ring[a], p & 3);
-    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 22;           // 10 bits
+    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);           // 10 bits
     const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);  // 10 bits
     uint32_t d3 = kNoLink, d2 = kNoLink;
     // ds_wrxchg_rtn_b32: lanes sharing a slot are served in ascending lane order (see above)
@@ -757,6 +767,9 @@ constexpr uint32_t kWgResN     = 2 * kWgPool;     // results of two consecutive 
 constexpr uint32_t kWgBitWords = 256;             // 8192-bit ring, quarters of 2048 bits
 constexpr uint32_t kOpen       = 1023;            // jump code of an open match
 constexpr uint32_t kExtOpen    = 63;              // extension code of an open match
+#ifndef LZS_SUBSTEPS
+#define LZS_SUBSTEPS 1
+#endif
 constexpr uint32_t kExtMax     = 59;              // longest extension resolved in SEARCH
 
 struct __attribute__((aligned(16))) BlkLds {
@@ -771,6 +784,9 @@ struct __attribute__((aligned(16))) BlkLds {
     uint32_t chunk_bits[8];
     uint32_t nextp;                               // SEARCH work counter
     uint32_t bcast[8];
+#ifdef LZS_PAD_LDS
+    uint32_t pad[LZS_PAD_LDS / 4];                // occupancy experiments only
+#endif
 };
 
 __device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) % (kWgLinkN / 64u)) * 64u; }
@@ -859,7 +875,7 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
         deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
                p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
     }
-    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> 22;
+    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
     const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
     const uint32_t slot = wg_slot_base(B) + lane;
     if (wave == 4 || (h3 & 3u) == wave) {
@@ -877,6 +893,56 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
             d = p - old < kNoLink ? p - old : kNoLink;
         }
         L.link2[slot] = (uint16_t)d;
+    }
+}
+
+// EXTEND: a match that fills the search cap (12) may run on, and its token is only complete with
+// the whole length (:417-431).  SEARCH leaves bits 15.. of such results empty; this pass fills them
+// for the pool about to be parsed, for both chunks of the calling wave.  Consecutive positions
+// inside one long match all report 12 at the same offset, and their totals differ by one per
+// position, so only the first of each such run (per 64-position chunk) compares bytes -- up to
+// kTokenMax + kExtMax + 1 of them -- and the others derive theirs.  Beyond that the match is
+// "open" (finished serially in PARSE), and so is everything derived from an open one.
+__device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry, uint32_t npos, uint32_t n, uint32_t lane, uint32_t wave)
+{
+    constexpr uint32_t kRoom = kTokenMax + kExtMax + 1;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t gi = 256u * h + 64u * wave + lane;
+        if (64u * wave + 256u * h >= npos) continue;           // chunk past the end of the pool (uniform)
+        const uint32_t p = Pb + gi;
+        const uint32_t r = L.res[p & (kWgResN - 1)];
+        const uint32_t len = (r >> 11) & 15u, off = r & kWindow;
+        // positions before the entry were not searched: what is stored there is stale
+        const bool need = gi >= entry && gi < npos && len == kSearchCap && n - p > kSearchCap;
+        const uint64_t needs = __builtin_amdgcn_ballot_w64(need);
+        if (needs == 0ull) {
+            if (len > kTokenMax) L.res[p & (kWgResN - 1)] = r | ((len - kTokenMax) << 15);
+            continue;
+        }
+        const uint32_t left = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane - 1u) << 2), (int)r);
+        // the run goes on if the position before is complete the same way: 12 at the same offset
+        const bool head = need && !(lane > 0u && ((needs >> (lane - 1u)) & 1ull) != 0ull && ((left ^ r) & 0x7FFFu) == 0u);
+        uint32_t total = kSearchCap;
+        if (head) {
+            const uint32_t room = n - p < kRoom ? n - p : kRoom;
+            for (;;) {
+                uint32_t a0, a1, a2, b0, b1, b2;
+                ringm_read12(L.ring, p + total, a0, a1, a2);
+                ringm_read12(L.ring, p + total - off, b0, b1, b2);
+                uint32_t e = lcp12(a0 ^ b0, a1 ^ b1, a2 ^ b2);
+                e = e < 12u ? e : 12u;
+                e = e < room - total ? e : room - total;
+                total += e;
+                if (e < 12u || total >= room) break;
+            }
+        }
+        const uint64_t heads = __builtin_amdgcn_ballot_w64(head) & ((2ull << lane) - 1ull);
+        const uint32_t hp = heads ? 63u - (uint32_t)__builtin_clzll(heads) : lane;   // head of my run
+        const uint32_t th = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hp << 2), (int)total);
+        uint32_t ext = len >= kTokenMax ? len - kTokenMax : 0u;
+        if (need) ext = th >= kRoom ? kExtOpen : th - (lane - hp) - kTokenMax;
+        if (ext) L.res[p & (kWgResN - 1)] = r | (ext << 15);
     }
 }
 
@@ -927,6 +993,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
             const bool take = !busy && np < pend;
             PROF_COUNT(9, 1);
             PROF_COUNT(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(take)));
+            PROF_T0;
             if (take) {                                                  // exec-masked: direct writes, no selects
                 p = np;
                 ringm_read12(L.ring, p, t0, t1, t2);
@@ -951,11 +1018,9 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
                 // chains that are empty inside the window are skipped here, not discovered by a step
                 const bool walk3 = lim >= 3u && !capped && l3 <= reach;
                 const bool walk2 = lim >= 2u && !capped && !seeded && l2 <= reach;
-                // no candidate anywhere: a literal, or the offset-1 match as it stands (a match that
-                // fills the 12-byte cap still goes through a step so that its extension is measured)
-                const bool instant = !walk3 && !walk2 && !(seeded && len1 == kSearchCap);
-                if (instant)
-                    L.res[p & (kWgResN - 1)] = seeded ? (1u | (len1 << 11) | ((len1 >= kTokenMax ? len1 - kTokenMax : 0u) << 15)) : 0u;
+                // no candidate anywhere: a literal, or the offset-1 match as it stands
+                const bool instant = !walk3 && !walk2;
+                if (instant) L.res[p & (kWgResN - 1)] = seeded ? (1u | (len1 << 11)) : 0u;
                 three = walk3;
                 first2 = walk2 ? l2 : kNoLink;
                 dist = walk3 ? l3 : first2;
@@ -969,57 +1034,49 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
                 links = walk3 ? L.link3 : L.link2;
                 busy = !instant;
             }
+            PROF_T1(14);
         }
         if (pool_done && __builtin_amdgcn_ballot_w64(busy && p < Pb) == 0ull) break;
-        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) continue;
         PROF_COUNT(11, 1);
         PROF_COUNT(8 + 4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy)));
-        const uint32_t cum2 = cum + dist;
-        const bool inwin = busy && cum2 <= reach;
-        uint32_t w0, w1, w2;
-        ringm_read12(L.ring, p - (inwin ? cum2 : 0u), w0, w1, w2);
-        int32_t at = (int32_t)myslot - (int32_t)(inwin ? cum2 : 0u);
-        at = at < 0 ? at + (int32_t)kWgLinkN : at;
-        const uint32_t nd = links[at];
-        uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
-        len = len < lim ? len : lim;
-        const bool takeit = inwin && len > beat;
-        best_len = takeit ? len : best_len;
-        best_off = takeit ? cum2 : best_off;
-        beat = takeit ? len : beat;
-        const bool ended = !inwin || len >= stop_at;
-        // nothing >= 2 so far and the 3-byte chain is exhausted: restart on the 2-byte chain
-        const bool fallback = busy && ended && three && best_len < 2u;
-        const bool finish = busy && ended && !fallback;
-        cum = fallback ? 0u : cum2;
-        dist = fallback ? first2 : nd;
-        three = three && !fallback;
-        beat = fallback ? 1u : beat;
-        stop_at = fallback ? 2u : stop_at;
-        links = fallback ? L.link2 : links;
-        if (finish) {
-            // a match that fills the search cap may run on: measure it (up to kExtMax more
-            // than the 8 of the first code) so the token is complete (:417-431)
-            uint32_t ext = best_len >= kTokenMax ? best_len - kTokenMax : 0u;
-            if (best_len == kSearchCap && n - p > kSearchCap) {
-                const uint32_t room = n - p < kTokenMax + kExtMax + 1 ? n - p : kTokenMax + kExtMax + 1;
-                uint32_t total = kSearchCap;
-                for (;;) {
-                    uint32_t a0, a1, a2, b0, b1, b2;
-                    ringm_read12(L.ring, p + total, a0, a1, a2);
-                    ringm_read12(L.ring, p + total - best_off, b0, b1, b2);
-                    uint32_t e = lcp12(a0 ^ b0, a1 ^ b1, a2 ^ b2);
-                    e = e < 12u ? e : 12u;
-                    e = e < room - total ? e : room - total;
-                    total += e;
-                    if (e < 12u || total >= room) break;
+        PROF_T0B;
+        PROF_STAMP0;
+#pragma unroll
+        for (int sub = 0; sub < LZS_SUBSTEPS; sub++) {
+            if (busy) {                                        // exec-masked: idle lanes touch nothing
+                const uint32_t cum2 = cum + dist;
+                const bool inwin = cum2 <= reach;
+                const uint32_t back = inwin ? cum2 : 0u;
+                uint32_t w0, w1, w2;
+                ringm_read12(L.ring, p - back, w0, w1, w2);
+                const uint32_t at = myslot - back;
+                const uint32_t nd = links[at < at + kWgLinkN ? at : at + kWgLinkN];
+                PROF_STAMP(16);
+                uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
+                len = len < lim ? len : lim;
+                len = inwin ? len : 0u;
+                PROF_STAMP(17);
+                const bool takeit = len > beat;
+                best_len = takeit ? len : best_len;
+                best_off = takeit ? cum2 : best_off;
+                beat = takeit ? len : beat;
+                const bool ended = !inwin || len >= stop_at;
+                PROF_STAMP(18);
+                if (ended) {
+                    if (three && best_len < 2u) {
+                        // nothing >= 2 and the 3-byte chain is exhausted: restart on the 2-byte chain
+                        cum = 0u; dist = first2; three = false; beat = 1u; stop_at = 2u; links = L.link2;
+                    } else {
+                        L.res[p & (kWgResN - 1)] = best_off | (best_len << 11);   // extension: wg_extend()
+                        busy = false;
+                    }
+                } else {
+                    cum = cum2; dist = nd;
                 }
-                ext = total - kTokenMax;
             }
-            const uint32_t code = ext > kExtMax ? kExtOpen : ext;
-            L.res[p & (kWgResN - 1)] = best_off | (best_len << 11) | (code << 15);
         }
-        busy = busy && !finish;
+        PROF_STAMP(19);
+        PROF_T1B(15);
     }
     W.busy = busy; W.three = three;
     W.p = p; W.t0 = t0; W.t1 = t1; W.t2 = t2; W.lim = lim; W.reach = reach; W.myslot = myslot; W.first2 = first2;
@@ -1132,6 +1189,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         // the m-th token start of its chunk from the kept doubling tables -- so lane order is
         // token order and the bit offsets are a prefix sum.
         const uint32_t npos = pend - Pb;
+        wg_extend(L, Pb, c - Pb, npos, n, lane, wave);                 // each thread completes the results it reads below
         while (c < pend && o.flushed < o.cap) {
             const uint32_t entry = c - Pb;
             uint32_t rr[2], T[2][6];

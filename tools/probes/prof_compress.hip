@@ -16,7 +16,7 @@ int main(int argc, char **argv)
     hipMalloc(&d_in, h.size()); hipMalloc(&d_out, (size_t)nb * stride); hipMalloc(&d_len, nb * 4);
     hipMemcpy(d_in, h.data(), h.size(), hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; rep++) {
-        unsigned long long zero[16] = {0};
+        unsigned long long zero[24] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(lzs_prof), zero, sizeof(zero));
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a);
@@ -24,7 +24,7 @@ int main(int argc, char **argv)
                            (const uint8_t *)d_in, (size_t)bl, (const uint32_t *)nullptr, bl, nb);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
-        unsigned long long p[16];
+        unsigned long long p[24];
         hipMemcpyFromSymbol(p, HIP_SYMBOL(lzs_prof), sizeof(p));
         const double nbytes = nb * 65536.0;
         double tot = 0; for (int i = 0; i < 8; i++) tot += (double)p[i];
@@ -33,6 +33,8 @@ int main(int argc, char **argv)
                p[0] / nbytes, p[1] / nbytes, p[2] / nbytes, p[5] / nbytes, p[3] / nbytes, p[6] / nbytes, p[7] / nbytes, p[4] / nbytes, tot / nbytes, p[13]);
         printf("  wave 0 per pool: refill passes %.2f (positions taken %.1f), step iterations %.2f (busy lanes %.1f)\n",
                (double)p[9] / p[13], (double)p[10] / p[13], (double)p[11] / p[13], (double)p[12] / (p[11] ? p[11] : 1));
+        printf("  wave 0 search: cycles per refill pass %.0f, per step iteration %.0f\n", (double)p[14] / (p[9] ? p[9] : 1), (double)p[15] / (p[11] ? p[11] : 1));
+        printf("  step sections (cycles per iteration): address+issue %.0f, compare %.0f, update %.0f, ended-block %.0f\n", (double)p[16] / p[11], (double)p[17] / p[11], (double)p[18] / p[11], (double)p[19] / p[11]);
     }
     return 0;
 }

@@ -82,6 +82,7 @@ int main(int argc, char **argv)
     use4 = argc > 6 ? atoi(argv[6]) : 0;
     const int rolling = argc > 7 ? atoi(argv[7]) : 0;
     const uint32_t poolsz = argc > 8 ? atoi(argv[8]) : 512;
+    const int halves = argc > 9 ? atoi(argv[9]) : 1;   /* walks per lane */
     uint8_t *buf = malloc((size_t)nb * bl);
     lzs_workload_fill(buf, cls, 0x4C5A5331ull, 0, nb, bl, 8);
     uint16_t *steps = malloc(2 * bl);
@@ -95,7 +96,7 @@ int main(int argc, char **argv)
             hist[s == 0 ? 0 : s <= 2 ? 1 : s <= 4 ? 2 : s <= 8 ? 3 : s <= 16 ? 4 : s <= 32 ? 5 : s <= 64 ? 6 : 7] += s ? s : 1;
         }
         /* scheduling: 4 waves x 64 lanes, lock-step round robin over waves */
-        static uint32_t rem[4][64], own[4][64];
+        static uint32_t rem[4][256], own[4][256];
         memset(rem, 0, sizeof rem);
         uint32_t nextp = 0;
         const uint32_t pool = rolling == 1 ? bl : poolsz;
@@ -110,19 +111,21 @@ int main(int argc, char **argv)
             while (!(done[0] && done[1] && done[2] && done[3])) {
                 for (int w = 0; w < 4; w++) {
                     if (done[w]) continue;
-                    uint32_t nidle = 0; for (int l = 0; l < 64; l++) nidle += rem[w][l] == 0;
-                    if (!pool_done[w] && (nidle >= refill_min || nidle == 64)) {
-                        uint32_t basep = nextp; nextp += nidle; pool_done[w] = basep + nidle >= pend;
-                        uint32_t r = 0;
-                        for (int l = 0; l < 64; l++) if (rem[w][l] == 0) { uint32_t np = basep + r++; if (np < pend) { rem[w][l] = steps[np]; own[w][l] = k; } }
-                        passes++;
+                    for (int h = 0; h < halves; h++) {
+                        uint32_t nidle = 0; for (int l = 64 * h; l < 64 * h + 64; l++) nidle += rem[w][l] == 0;
+                        if (!pool_done[w] && (nidle >= refill_min || nidle == 64)) {
+                            uint32_t basep = nextp; nextp += nidle; pool_done[w] = basep + nidle >= pend;
+                            uint32_t r = 0;
+                            for (int l = 64 * h; l < 64 * h + 64; l++) if (rem[w][l] == 0) { uint32_t np = basep + r++; if (np < pend) { rem[w][l] = steps[np]; own[w][l] = k; } }
+                            passes++;
+                        }
                     }
                     uint32_t nbusy = 0, nold = 0;
-                    for (int l = 0; l < 64; l++) { nbusy += rem[w][l] != 0; nold += rem[w][l] != 0 && (last || own[w][l] + lag <= k); }
+                    for (int l = 0; l < 64 * halves; l++) { nbusy += rem[w][l] != 0; nold += rem[w][l] != 0 && (last || own[w][l] + lag <= k); }
                     if (pool_done[w] && nold == 0) { done[w] = 1; continue; }
                     if (nbusy == 0) continue;
                     iters++; busy_lane_steps += nbusy;
-                    for (int l = 0; l < 64; l++) if (rem[w][l]) rem[w][l]--;
+                    for (int l = 0; l < 64 * halves; l++) if (rem[w][l]) rem[w][l]--;
                 }
             }
         }
