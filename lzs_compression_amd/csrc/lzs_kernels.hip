@@ -768,7 +768,7 @@ constexpr uint32_t kWgBitWords = 256;             // 8192-bit ring, quarters of 
 constexpr uint32_t kOpen       = 1023;            // jump code of an open match
 constexpr uint32_t kExtOpen    = 63;              // extension code of an open match
 #ifndef LZS_SUBSTEPS
-#define LZS_SUBSTEPS 1
+#define LZS_SUBSTEPS 3
 #endif
 constexpr uint32_t kExtMax     = 59;              // longest extension resolved in SEARCH
 
@@ -911,13 +911,16 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         const uint32_t gi = 256u * h + 64u * wave + lane;
         if (64u * wave + 256u * h >= npos) continue;           // chunk past the end of the pool (uniform)
         const uint32_t p = Pb + gi;
-        const uint32_t r = L.res[p & (kWgResN - 1)];
-        const uint32_t len = (r >> 11) & 15u, off = r & kWindow;
+        // SEARCH stored (len << 16) | (0xFFFF - offset); offset 0 = no match
+        const uint32_t k = L.res[p & (kWgResN - 1)];
+        const uint32_t off = 0xFFFFu - (k & 0xFFFFu);
+        const uint32_t len = off ? k >> 16 : 0u;
+        const uint32_t r = off | (len << 11);
         // positions before the entry were not searched: what is stored there is stale
         const bool need = gi >= entry && gi < npos && len == kSearchCap && n - p > kSearchCap;
         const uint64_t needs = __builtin_amdgcn_ballot_w64(need);
         if (needs == 0ull) {
-            if (len > kTokenMax) L.res[p & (kWgResN - 1)] = r | ((len - kTokenMax) << 15);
+            L.res[p & (kWgResN - 1)] = r | ((len > kTokenMax ? len - kTokenMax : 0u) << 15);
             continue;
         }
         const uint32_t left = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane - 1u) << 2), (int)r);
@@ -942,27 +945,47 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         const uint32_t th = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hp << 2), (int)total);
         uint32_t ext = len >= kTokenMax ? len - kTokenMax : 0u;
         if (need) ext = th >= kRoom ? kExtOpen : th - (lane - hp) - kTokenMax;
-        if (ext) L.res[p & (kWgResN - 1)] = r | (ext << 15);
+        L.res[p & (kWgResN - 1)] = r | (ext << 15);
     }
 }
 
 // One lane's SEARCH state.  It lives in registers across pools: a walk that is still going when
 // its wave runs out of fresh positions is carried into the SEARCH of the next pool.
+//
+// The step is written for LATENCY, not instruction count: with 5 workgroups per CU a wave has at
+// most four neighbours on its SIMD, and measured on gfx950 a lone wave pays 4 cycles per VALU or
+// SALU instruction but ~28 for compare -> s_and -> select, ~35 for an exec-masked region and ~40
+// for a branch on a vector compare (tools/probes/lat_probe.hip).  So there is no boolean algebra
+// on lane masks and no branch inside a step: every predicate is one compare consumed by selects,
+// conditions are folded into the data (an out-of-window candidate compares with length cap 0),
+// the best match is one v_max over a packed key, and idle lanes run along harmlessly, storing to
+// a dummy word.
 struct Walk {
-    bool busy, three;
-    uint32_t p, t0, t1, t2, lim, reach, myslot, first2;
-    uint32_t cum, dist, best_len, best_off;
-    // per walk, kept instead of being re-derived each step: the length a match must exceed,
-    // the length that ends the walk, and which link array is being followed
-    uint32_t beat, stop_at;
-    const uint16_t *links;
+    uint32_t p, t0, t1, t2;      // position and its 12 bytes
+    uint32_t reach, myslot;      // window reach (<= 2047) and link slot of p
+    uint32_t cum, dist;          // distance walked so far, link to the next candidate
+    // best so far as (len << 16) | (0xFFFF - offset): candidates come nearest first, so a longer
+    // match wins and an equally long farther one does not.  0x2FFFF = "3-byte chain, nothing yet"
+    // (only a length >= 3 beats it), 0x1FFFF = "2-byte chain, nothing yet".
+    uint32_t key;
+    uint32_t cap;                // length that ends the walk: min(remaining, 12), or 2 on the 2-byte chain
+    uint32_t first2;             // where the 2-byte chain starts (kNoLink: nowhere)
+    const uint16_t *links;       // link array being followed
+    uint32_t *resp;              // where the result goes; the dummy word while the lane is idle
 };
+constexpr uint32_t kKeyNone3 = 0x2FFFFu, kKeyNone2 = 0x1FFFFu;
+
+// Where an idle lane's stores go: a word of its own in exitfn[], which is only live inside PARSE.
+__device__ __forceinline__ uint32_t *wg_dummy(BlkLds &L) { return reinterpret_cast<uint32_t *>(L.exitfn) + threadIdx.x; }
+
+template <class T> __device__ __forceinline__ T opaque(T x) { asm volatile("" : "+v"(x)); return x; }
 
 // SEARCH: every wave pulls positions of [Pb, pend) from L.nextp.  A wave leaves when the pool has
 // no fresh position left and none of its lanes still walks for a position before Pb (those belong
 // to the pool that is parsed next); walks for positions of this pool may be left unfinished.
 // The longest walk of a pool (about 30 steps in text, against 5.5 on average) then no longer
-// holds up 255 other lanes at the end of every pool.
+// holds up 255 other lanes at the end of every pool.  Results are stored as raw keys; EXTEND
+// turns them into off | len << 11 | ext << 15.
 #ifdef LZS_PROFILE
 #define SEARCH_PROF_PARAMS , unsigned long long *prof_acc
 #define SEARCH_PROF_ARGS , prof_acc
@@ -973,16 +996,16 @@ struct Walk {
 __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint32_t pend, uint32_t n, uint32_t lane SEARCH_PROF_PARAMS)
 {
     const uint32_t slot0 = wg_slot_base(Pb);
+    uint32_t *const dummy = wg_dummy(L);
     bool pool_done = false;
-    bool busy = W.busy, three = W.three;
-    uint32_t p = W.p, t0 = W.t0, t1 = W.t1, t2 = W.t2, lim = W.lim, reach = W.reach, myslot = W.myslot, first2 = W.first2;
-    uint32_t cum = W.cum, dist = W.dist, best_len = W.best_len, best_off = W.best_off;
-    uint32_t beat = W.beat, stop_at = W.stop_at;
+    uint32_t p = W.p, t0 = W.t0, t1 = W.t1, t2 = W.t2, reach = W.reach, myslot = W.myslot;
+    uint32_t cum = W.cum, dist = W.dist, key = W.key, cap = W.cap, first2 = W.first2;
     const uint16_t *links = W.links;
+    uint32_t *resp = W.resp;
     for (;;) {
-        const uint64_t idle = __builtin_amdgcn_ballot_w64(!busy);
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(resp == dummy);
         const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
-        if (!pool_done && (nidle >= kRefillMin || nidle == 64u)) {
+        if (!pool_done && nidle >= kRefillMin) {
             uint32_t basep = 0;
             if (lane == 0) basep = __hip_atomic_fetch_add(&L.nextp, nidle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             basep = uniform(basep);
@@ -990,7 +1013,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                   __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t np = basep + rank;
-            const bool take = !busy && np < pend;
+            const bool take = resp == dummy && np < pend;
             PROF_COUNT(9, 1);
             PROF_COUNT(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(take)));
             PROF_T0;
@@ -1002,7 +1025,7 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
                 sl = sl >= kWgLinkN ? sl - kWgLinkN : sl;
                 myslot = sl;
                 const uint32_t l3 = L.link3[sl], l2 = L.link2[sl];
-                lim = n - p < kSearchCap ? n - p : kSearchCap;
+                const uint32_t lim = n - p < kSearchCap ? n - p : kSearchCap;
                 // offset 1 first: common prefix of the text with itself shifted by one byte.  It
                 // can only reach 2 if the byte before equals the next two, which is rare in text:
                 // the 12-byte form is computed only when some lane needs it.
@@ -1018,70 +1041,57 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
                 // chains that are empty inside the window are skipped here, not discovered by a step
                 const bool walk3 = lim >= 3u && !capped && l3 <= reach;
                 const bool walk2 = lim >= 2u && !capped && !seeded && l2 <= reach;
-                // no candidate anywhere: a literal, or the offset-1 match as it stands
-                const bool instant = !walk3 && !walk2;
-                if (instant) L.res[p & (kWgResN - 1)] = seeded ? (1u | (len1 << 11)) : 0u;
-                three = walk3;
                 first2 = walk2 ? l2 : kNoLink;
                 dist = walk3 ? l3 : first2;
                 cum = 0u;
-                best_len = seeded ? len1 : 0u;
-                best_off = seeded ? 1u : 0u;
-                // 3-byte chain: a match must beat max(best, 2) and the cap ends the walk (:337-345);
-                // 2-byte chain: the first verified candidate (>= 2) is the answer
-                beat = walk3 ? (seeded ? len1 : 2u) : 1u;
-                stop_at = walk3 ? lim : 2u;
+                // 3-byte chain: only a longer match than the seed (or than 2) counts and the cap ends
+                // the walk (:337-345); 2-byte chain: the first verified candidate is the answer
+                key = seeded ? ((len1 << 16) | 0xFFFEu) : (walk3 ? kKeyNone3 : kKeyNone2);
+                cap = walk3 ? lim : 2u;
                 links = walk3 ? L.link3 : L.link2;
-                busy = !instant;
+                uint32_t *const slot = &L.res[p & (kWgResN - 1)];
+                *slot = key;                                             // final if there is no chain to walk
+                resp = (walk3 || walk2) ? slot : dummy;
             }
             PROF_T1(14);
         }
-        if (pool_done && __builtin_amdgcn_ballot_w64(busy && p < Pb) == 0ull) break;
+        if (pool_done && __builtin_amdgcn_ballot_w64(resp != dummy && p < Pb) == 0ull) break;
         PROF_COUNT(11, 1);
-        PROF_COUNT(8 + 4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy)));
+        PROF_COUNT(8 + 4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(resp != dummy)));
         PROF_T0B;
-        PROF_STAMP0;
 #pragma unroll
         for (int sub = 0; sub < LZS_SUBSTEPS; sub++) {
-            if (busy) {                                        // exec-masked: idle lanes touch nothing
-                const uint32_t cum2 = cum + dist;
-                const bool inwin = cum2 <= reach;
-                const uint32_t back = inwin ? cum2 : 0u;
-                uint32_t w0, w1, w2;
-                ringm_read12(L.ring, p - back, w0, w1, w2);
-                const uint32_t at = myslot - back;
-                const uint32_t nd = links[at < at + kWgLinkN ? at : at + kWgLinkN];
-                PROF_STAMP(16);
-                uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
-                len = len < lim ? len : lim;
-                len = inwin ? len : 0u;
-                PROF_STAMP(17);
-                const bool takeit = len > beat;
-                best_len = takeit ? len : best_len;
-                best_off = takeit ? cum2 : best_off;
-                beat = takeit ? len : beat;
-                const bool ended = !inwin || len >= stop_at;
-                PROF_STAMP(18);
-                if (ended) {
-                    if (three && best_len < 2u) {
-                        // nothing >= 2 and the 3-byte chain is exhausted: restart on the 2-byte chain
-                        cum = 0u; dist = first2; three = false; beat = 1u; stop_at = 2u; links = L.link2;
-                    } else {
-                        L.res[p & (kWgResN - 1)] = best_off | (best_len << 11);   // extension: wg_extend()
-                        busy = false;
-                    }
-                } else {
-                    cum = cum2; dist = nd;
-                }
-            }
+            // One step = one candidate, for all 64 lanes alike.
+            const uint32_t cum2 = cum + dist;
+            const bool inwin = cum2 <= reach;
+            const uint32_t back = inwin ? cum2 : 0u;          // out of the window: look at p itself ...
+            const uint32_t capx = inwin ? cap : 0u;           // ... and count none of it
+            uint32_t w0, w1, w2;
+            ringm_read12(L.ring, p - back, w0, w1, w2);
+            const uint32_t at = myslot - back;
+            const uint32_t nd = links[at < at + kWgLinkN ? at : at + kWgLinkN];
+            uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
+            len = len < capx ? len : capx;
+            const uint32_t cand = (len << 16) | (0xFFFFu - back);
+            key = key > cand ? key : cand;
+            *resp = key;
+            // the walk ends at the cap, or where the chain leaves the window (capx = 0 = len)
+            const uint32_t kend = opaque(len == capx ? key : 0u);
+            // nothing on the 3-byte chain: restart on the 2-byte chain
+            const bool fallback = kend == kKeyNone3;
+            const uint32_t kfin = opaque(fallback ? 0u : kend);
+            key = fallback ? kKeyNone2 : key;
+            cap = fallback ? 2u : cap;
+            cum = fallback ? 0u : cum2;
+            dist = fallback ? first2 : nd;
+            links = fallback ? L.link2 : links;
+            resp = kfin != 0u ? dummy : resp;                  // ended for good: the lane is idle
         }
-        PROF_STAMP(19);
         PROF_T1B(15);
     }
-    W.busy = busy; W.three = three;
-    W.p = p; W.t0 = t0; W.t1 = t1; W.t2 = t2; W.lim = lim; W.reach = reach; W.myslot = myslot; W.first2 = first2;
-    W.cum = cum; W.dist = dist; W.best_len = best_len; W.best_off = best_off;
-    W.beat = beat; W.stop_at = stop_at; W.links = links;
+    W.p = p; W.t0 = t0; W.t1 = t1; W.t2 = t2; W.reach = reach; W.myslot = myslot;
+    W.cum = cum; W.dist = dist; W.key = key; W.cap = cap; W.first2 = first2;
+    W.links = links; W.resp = resp;
 }
 
 __global__ __launch_bounds__(kWgThreads)
@@ -1122,9 +1132,9 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     // The pools are pipelined: while pool k is in SEARCH, pool k-1 (searched in the round before,
     // except for the walks carried over, which end in this round's SEARCH) waits for PARSE + PACK.
     Walk W;
-    W.busy = false; W.three = false;
-    W.p = 0; W.t0 = W.t1 = W.t2 = 0; W.lim = 0; W.reach = 0; W.myslot = 0; W.first2 = kNoLink;
-    W.cum = 0; W.dist = kNoLink; W.best_len = 0; W.best_off = 0; W.beat = 1; W.stop_at = 2; W.links = L.link2;
+    W.p = 0; W.t0 = W.t1 = W.t2 = 0; W.reach = 0; W.myslot = 0;
+    W.cum = 0; W.dist = kNoLink; W.key = 0; W.cap = 0; W.first2 = kNoLink;
+    W.links = L.link2; W.resp = wg_dummy(L);
     bool pending = false;                    // a searched pool waits for PARSE
     uint32_t Pb = 0, pend = 0;               // that pool
     const uint32_t nup = (n + 63u) & ~63u;
@@ -1344,7 +1354,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         PROF_COUNT(13, 1);
         // the pool just searched is parsed next, unless an open match ran past all of it
         Pb = Sb; pend = send; pending = fresh;
-        if (pending && c >= pend) { pending = false; W.busy = false; }
+        if (pending && c >= pend) { pending = false; W.resp = wg_dummy(L); }
     }
     if (wave == 0) { PROF_DONE; }
 
