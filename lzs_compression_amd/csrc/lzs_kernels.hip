@@ -853,6 +853,79 @@ __device__ __forceinline__ void wave_refill(BlkLds &L, const uint8_t *src, uint3
     __builtin_amdgcn_wave_barrier();
 }
 
+template <class T> __device__ __forceinline__ T opaque(T x) { asm volatile("" : "+v"(x)); return x; }
+
+// Where an idle lane's stores go: a word of its own in exitfn[], which is only live inside PARSE.
+__device__ __forceinline__ uint32_t *wg_dummy(BlkLds &L) { return reinterpret_cast<uint32_t *>(L.exitfn) + threadIdx.x; }
+
+// BUILD for the batches [B0, Be) by one of the four waves, written for latency like the SEARCH
+// step.  Waves 0 and 1 keep the 3-byte chain, waves 2 and 3 the 2-byte chain, each the buckets of
+// one parity, so every bucket is still chained by one wave's in-order instruction stream.  No
+// exec-masked regions and no branches inside the loop: a lane that must not insert (foreign
+// bucket, run interior, end of input) exchanges with its dummy word instead and its link goes
+// there too.  Whether a position is inside a run is read off ballots of "this byte equals the
+// next" over three neighbouring batches.  The text is read two batches ahead and the link of a
+// batch is stored one iteration after its exchange was issued, so LDS latency overlaps the
+// arithmetic.  Same chains as wg_build64().
+__device__ __forceinline__ void wg_build_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t n, uint32_t lane, uint32_t wave)
+{
+    uint32_t *const dummy = wg_dummy(L);
+    uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
+    const bool two = wave >= 2u;                               // uniform
+    const uint32_t parity = wave & 1u;
+    uint32_t *const heads = two ? L.head2 : L.head3;
+    uint16_t *const links = two ? L.link2 : L.link3;
+    const uint32_t tail = two ? 1u : 2u;                       // p + tail < n: the whole gram is input
+    const auto text4 = [&](uint32_t q) {
+        const uint32_t a = (q & kRingMask) >> 2;
+        return __builtin_amdgcn_alignbyte(L.ring[a + 1], L.ring[a], q);
+    };
+    // bit l: byte B+l equals byte B+l+1, and both are input
+    const auto eqnext = [&](uint32_t q, uint32_t t) {
+        const uint32_t diff = ((t ^ (t >> 8)) & 0xFFu) | (q + 1u < n ? 0u : 1u);
+        return __builtin_amdgcn_ballot_w64(diff == 0u);
+    };
+    uint64_t eprev = 0;
+    if (B0 >= 64u) eprev = eqnext(B0 - 64u + lane, text4(B0 - 64u + lane));
+    uint32_t tcur = text4(B0 + lane);
+    uint64_t ecur = eqnext(B0 + lane, tcur);
+    uint32_t tnext = text4(B0 + 64u + lane);
+    // lane l needs the 13 bits from bit l-1 of (enext : ecur : eprev >> 63)
+    const bool first = lane == 0u, low = lane <= 32u;
+    const uint32_t shift = (lane + 31u) & 31u;
+    // the exchange of the batch before, not yet turned into a link
+    uint32_t was = 0, was_p = 0, was_out = 1;
+    uint16_t *was_link = dummy16;
+    for (uint32_t B = B0; B < Be; B += 64u) {
+        const uint32_t p = B + lane;
+        const uint32_t tnext2 = text4(p + 128u);
+        const uint64_t enext = eqnext(p + 64u, tnext);
+        const uint32_t w0 = (uint32_t)(eprev >> 32), w1 = (uint32_t)ecur, w2 = (uint32_t)(ecur >> 32), w3 = (uint32_t)enext;
+        const uint32_t lo = first ? w0 : (low ? w1 : w2), hi = first ? w1 : (low ? w2 : w3);
+        const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
+        // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
+        const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
+        const uint32_t h3 = ((tcur & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
+        const uint32_t h2 = (((tcur & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
+        const uint32_t h = two ? h2 : h3;
+        const uint32_t foreign = (h & 1u) ^ parity;
+        const uint32_t out = opaque(skip | (p + tail < n ? 0u : 1u));
+        uint32_t *const ha = (foreign | out) == 0u ? &heads[h] : dummy;
+        const uint32_t old = __hip_atomic_exchange(ha, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint16_t *const la = foreign == 0u ? &links[wg_slot_base(B) + lane] : dummy16;
+        {
+            uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
+            d = was_out == 0u ? d : kNoLink;
+            *was_link = (uint16_t)d;
+        }
+        was = old; was_p = p; was_out = out; was_link = la;
+        eprev = ecur; ecur = enext; tcur = tnext; tnext = tnext2;
+    }
+    uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
+    d = was_out == 0u ? d : kNoLink;
+    *was_link = (uint16_t)d;
+}
+
 // Insert the 64 positions starting at B.  `wave` < 4: only buckets owned by that wave
 // (called by all four waves); wave == 4: every bucket (called by one wave alone).
 __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, uint32_t lane, uint32_t wave)
@@ -974,11 +1047,6 @@ struct Walk {
     uint32_t *resp;              // where the result goes; the dummy word while the lane is idle
 };
 constexpr uint32_t kKeyNone3 = 0x2FFFFu, kKeyNone2 = 0x1FFFFu;
-
-// Where an idle lane's stores go: a word of its own in exitfn[], which is only live inside PARSE.
-__device__ __forceinline__ uint32_t *wg_dummy(BlkLds &L) { return reinterpret_cast<uint32_t *>(L.exitfn) + threadIdx.x; }
-
-template <class T> __device__ __forceinline__ T opaque(T x) { asm volatile("" : "+v"(x)); return x; }
 
 // SEARCH: every wave pulls positions of [Pb, pend) from L.nextp.  A wave leaves when the pool has
 // no fresh position left and none of its lanes still walks for a position before Pb (those belong
@@ -1171,7 +1239,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             __syncthreads();
             PROF_MARK(0);
             // every wave walks all batches, inserting into its own buckets
-            for (uint32_t B = next; B < Se; B += 64) wg_build64(L, B, n, lane, wave);
+            { PROF_T0; PROF_COUNT(17, (Se - next) >> 6); wg_build_range(L, next, Se, n, lane, wave); PROF_T1(16); }
             next = Se;
         }
         const uint32_t send = Se < n ? Se : n;

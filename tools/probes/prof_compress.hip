@@ -34,7 +34,7 @@ int main(int argc, char **argv)
         printf("  wave 0 per pool: refill passes %.2f (positions taken %.1f), step iterations %.2f (busy lanes %.1f)\n",
                (double)p[9] / p[13], (double)p[10] / p[13], (double)p[11] / p[13], (double)p[12] / (p[11] ? p[11] : 1));
         printf("  wave 0 search: cycles per refill pass %.0f, per step iteration %.0f\n", (double)p[14] / (p[9] ? p[9] : 1), (double)p[15] / (p[11] ? p[11] : 1));
-        printf("  step sections (cycles per iteration): address+issue %.0f, compare %.0f, update %.0f, ended-block %.0f\n", (double)p[16] / p[11], (double)p[17] / p[11], (double)p[18] / p[11], (double)p[19] / p[11]);
+        printf("  build: %.0f cycles per batch of 64 (%.2f batches per pool)\n", (double)p[16] / (p[17] ? p[17] : 1), (double)p[17] / p[13]);
     }
     return 0;
 }
