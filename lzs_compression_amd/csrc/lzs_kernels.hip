@@ -423,8 +423,8 @@ __device__ __forceinline__ void br_finish(BitRing &e, uint32_t *words, uint32_t 
 // ---------------------------------------------------------------------------------
 #ifdef LZS_PROFILE
 // Diagnostic build only (tools/probes/prof_compress): per-phase cycle sums over all waves.
-__device__ unsigned long long lzs_prof[24];
-#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
+__device__ unsigned long long lzs_prof[32];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[32] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
 #define PROF_MARK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; } while (0)
 #define PROF_COUNT(i, v) do { prof_acc[i] += (v); } while (0)
 #define PROF_T0 unsigned long long prof_u = __builtin_readcyclecounter()
@@ -435,7 +435,7 @@ __device__ unsigned long long lzs_prof[24];
 #define PROF_T1C(i) do { prof_acc[i] += __builtin_readcyclecounter() - prof_w; } while (0)
 #define PROF_STAMP0 unsigned long long prof_s = __builtin_readcyclecounter()
 #define PROF_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_s; prof_s = t_; } while (0)
-#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 24; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
+#define PROF_DONE do { if (lane == 0) for (int i_ = 0; i_ < 32; i_++) atomicAdd(&lzs_prof[i_], prof_acc[i_]); } while (0)
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
@@ -462,7 +462,10 @@ constexpr uint32_t kLinkN     = 2560;            // 40 x 64 >= 2047 + kPool
 constexpr uint32_t kHead3     = 1u << LZS_HEAD3_BITS;
 constexpr uint32_t kHead2     = 1u << LZS_HEAD2_BITS;
 constexpr uint32_t kNoLink    = 0xFFFFu;
-constexpr uint32_t kRefillMin = 32;              // idle lanes that justify a refill pass
+#ifndef LZS_REFILL_MIN
+#define LZS_REFILL_MIN 32
+#endif
+constexpr uint32_t kRefillMin = LZS_REFILL_MIN;  // idle lanes that justify a refill pass
 
 struct __attribute__((aligned(16))) ChainLds {
     uint32_t ring[kRingWords + 4];               // +16 B mirror of ring[0..15]: reads never wrap
@@ -1267,111 +1270,153 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         // the m-th token start of its chunk from the kept doubling tables -- so lane order is
         // token order and the bit offsets are a prefix sum.
         const uint32_t npos = pend - Pb;
+        PROF_STAMP0;
         wg_extend(L, Pb, c - Pb, npos, n, lane, wave);                 // each thread completes the results it reads below
+        PROF_STAMP(20);
         while (c < pend && o.flushed < o.cap) {
             const uint32_t entry = c - Pb;
-            uint32_t rr[2], T[2][6];
+            // Written for latency (see Walk): the two chunks of a wave go through every
+            // dependent cross-lane step side by side, predicates are single compares consumed
+            // by selects, and nothing is exec-masked.
+            uint32_t rr[2], T[2][6], t[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t gi = 256u * h + 64u * wave + lane;          // pool-relative position
-                const uint32_t r = L.res[(Pb + gi) & (kWgResN - 1)];
+                const uint32_t cb = 256u * h + 64u * wave;                 // pool-relative start of the chunk
+                const uint32_t inside = cb < npos ? (npos - cb < 64u ? npos - cb : 64u) : 0u;   // its positions in the pool
+                const uint32_t r = L.res[(Pb + cb + lane) & (kWgResN - 1)];
                 const uint32_t len = (r >> 11) & 15u, ext = r >> 15;
-                const uint32_t land = lane + (len < 2u ? 1u : (len < kTokenMax ? len : kTokenMax + ext));
+                uint32_t step = len < kTokenMax ? len : kTokenMax + ext;
+                step = len < 2u ? 1u : step;
+                const uint32_t land = lane + step;
                 // codes: < 64 next start inside the chunk; 0x100|j chain leaves at chunk offset j
                 // (j >= 64, or the end of the pool); 0x200|i open match at chunk offset i
-                uint32_t t = (land < 64u && gi - lane + land < npos) ? land : (0x100u | land);
-                if (len >= kTokenMax && ext == kExtOpen) t = 0x200u | lane;
-                if (gi >= npos) t = 0x100u | lane;
-                rr[h] = r;
+                uint32_t x = land < inside ? land : (0x100u | land);
+                x = ext == kExtOpen ? (0x200u | lane) : x;                 // ext is 63 only for an open match
+                x = lane < inside ? x : (0x100u | lane);
+                rr[h] = r; t[h] = x;
+            }
 #pragma unroll
-                for (int d = 0; d < 6; d++) {
-                    T[h][d] = t;
-                    const uint32_t via = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((t & 63u) << 2), (int)t);
-                    t = t < 64u ? via : t;
+            for (int d = 0; d < 6; d++) {
+                uint32_t via[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    T[h][d] = t[h];
+                    via[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((t[h] & 63u) << 2), (int)t[h]);
                 }
-                L.exitfn[gi] = (uint16_t)t;
+#pragma unroll
+                for (int h = 0; h < 2; h++) t[h] = t[h] < 64u ? via[h] : t[h];
             }
-            __syncthreads();
-            // walk the exit functions from the entry: at most one step per chunk
-            uint32_t my_entry[2] = {~0u, ~0u};
-            uint32_t pos = entry, chain_end = kOpen, open_at = 0;
-            while (pos < npos) {
-                const uint32_t k = pos >> 6;
-                if (k == wave) my_entry[0] = pos & 63u;
-                if (k == 4u + wave) my_entry[1] = pos & 63u;
-                const uint32_t x = uniform((uint32_t)L.exitfn[pos]);
-                if (x & 0x200u) { open_at = (k << 6) + (x & 63u); pos = ~0u; break; }
-                pos = (k << 6) + (x & 0xFFu);
-            }
-            if (pos != ~0u) chain_end = pos;
-            PROF_MARK(3);
-            // ---- PACK: lane m takes the m-th token of its chunk (formats: lzs-compression.c:365-431)
-            uint32_t headv[2], headw[2], tailv[2], tailw[2], incl[2];
+            // published per entry position: the pool-relative position the chain goes to next
+            // (>= npos: the pool is done), or 0x8000 | the position of an open match
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const bool entered = my_entry[h] != ~0u;
-                uint32_t node = entered ? my_entry[h] : 0x100u;
-#pragma unroll
-                for (int d = 0; d < 6; d++) {
-                    const uint32_t via = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node & 63u) << 2), (int)T[h][d]);
-                    node = (((lane >> d) & 1u) && node < 64u) ? via : node;
-                }
-                const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node & 63u) << 2), (int)rr[h]);
-                const uint32_t len = (r >> 11) & 15u, ext = r >> 15, off = r & kWindow;
-                const bool mine = node < 64u && !(len >= kTokenMax && ext == kExtOpen);
-                uint32_t hv = ring_byte(L.ring, Pb + 256u * h + 64u * wave + (node & 63u)) & 0xFFu, hw = 9, tv = 0, tw = 0;
-                if (len >= 2u) {
-                    const uint32_t ov = off <= kShortMax ? ((3u << 7) | off) : ((2u << 11) | off);
-                    const uint32_t ow = off <= kShortMax ? 9u : 13u;
-                    const uint32_t first = len < kTokenMax ? len : kTokenMax;
-                    const uint32_t lv = first <= 4 ? first - 2 : 0xCu + (first - 5);
-                    const uint32_t lw = first <= 4 ? 2u : 4u;
-                    hv = (ov << lw) | lv;
-                    hw = ow + lw;
-                    if (len >= kTokenMax) {                       // nibbles: 15 15 .. last
-                        const uint32_t full = ext / kNibbleMax;
-                        tv = (((1u << (4 * full)) - 1u) << 4) | (ext % kNibbleMax);
-                        tw = 4 * (full + 1);
-                    }
-                }
-                headv[h] = hv; headw[h] = mine ? hw : 0u; tailv[h] = tv; tailw[h] = mine ? tw : 0u;
-                incl[h] = wave_inclusive_sum(headw[h] + tailw[h]);
-                if (lane == 63) L.chunk_bits[4 * h + wave] = incl[h];
+                const uint32_t cb = 256u * h + 64u * wave;
+                const uint32_t v = (t[h] & 0x200u) ? (0x8000u | (cb + (t[h] & 63u))) : cb + (t[h] & 0xFFu);
+                L.exitfn[cb + lane] = (uint16_t)v;
             }
+            PROF_STAMP(21);
             __syncthreads();
-            uint32_t before[2] = {0, 0}, total = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 8; q++) {
-                const uint32_t cb = L.chunk_bits[q];
-                if (q < wave) before[0] += cb;
-                if (q < 4 + wave) before[1] += cb;
-                total += cb;
-            }
-            const uint32_t at0 = wg_bit_at(o);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t wsum = headw[h] + tailw[h];
-                if (wsum) {
-                    const uint32_t at = at0 + before[h] + incl[h] - wsum;
-                    bits_or(L.bits, kWgBitWords, at & 8191u, headv[h], headw[h]);
-                    if (tailw[h]) bits_or(L.bits, kWgBitWords, (at + headw[h]) & 8191u, tailv[h], tailw[h]);
-                }
-            }
-            o.head += total;
-            __syncthreads();
-            // complete quarters go out, one wave each
+            PROF_STAMP(22);
+            // complete quarters of the bit ring go out, one wave each: the bits of the round before
+            // are all in (barrier above), and nothing is added before the next barrier
             while (o.head >= 2048u) {
                 if (wave == ((o.flushed >> 8) & 3u)) wg_store_quarter(o, L, lane);
                 o.flushed += 256u;
                 o.head -= 2048u;
             }
+            // follow the published exits from the entry, one hop per chunk, in every lane alike
+            uint32_t node[2] = {0x100u, 0x100u};
+            uint32_t pos = entry;
+#pragma unroll
+            for (int hop = 0; hop < 8; hop++) {
+                const uint32_t k = pos < npos ? pos >> 6 : 0xFFu;
+                node[0] = k == wave ? pos & 63u : node[0];
+                node[1] = k == wave + 4u ? pos & 63u : node[1];
+                const uint32_t nx = L.exitfn[pos < kWgPool ? pos : kWgPool - 1u];
+                pos = k != 0xFFu ? nx : pos;
+            }
+            const uint32_t last = uniform(pos);
+            const uint32_t chain_end = (last & 0x8000u) ? kOpen : last;
+            const uint32_t open_at = last & 0x7FFFu;
+            PROF_STAMP(23);
+            PROF_MARK(3);
+            // ---- PACK: lane m takes the m-th token of its chunk (formats: lzs-compression.c:365-431)
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                uint32_t via[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    via[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node[h] & 63u) << 2), (int)T[h][d]);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t on = node[h] < 64u ? via[h] : node[h];
+                    node[h] = ((lane >> d) & 1u) ? on : node[h];
+                }
+            }
+            uint32_t valhi[2], vallo[2], width[2], incl[2], rtok[2], btok[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                rtok[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node[h] & 63u) << 2), (int)rr[h]);
+                btok[h] = ring_byte(L.ring, Pb + 256u * h + 64u * wave + (node[h] & 63u)) & 0xFFu;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t r = rtok[h];
+                const uint32_t len = (r >> 11) & 15u, ext = r >> 15, off = r & kWindow;
+                // match: offset field, first length code, extension nibbles 15 15 .. last
+                const uint32_t ov = off <= kShortMax ? ((3u << 7) | off) : ((2u << 11) | off);
+                const uint32_t ow = off <= kShortMax ? 9u : 13u;
+                const uint32_t first = len < kTokenMax ? len : kTokenMax;
+                const uint32_t lv = first <= 4u ? first - 2u : first + 7u;
+                const uint32_t lw = first <= 4u ? 2u : 4u;
+                const uint32_t full = (ext * 137u) >> 11;                  // ext / 15 for ext < 64
+                uint32_t tv = (((1u << (4u * full)) - 1u) << 4) | (ext - kNibbleMax * full);
+                uint32_t tw = 4u * (full + 1u);
+                tw = len < kTokenMax ? 0u : tw;
+                tv = len < kTokenMax ? 0u : tv;
+                uint32_t hv = (ov << lw) | lv, hw = ow + lw;
+                hv = len < 2u ? btok[h] : hv;                              // literal: 0 bbbbbbbb
+                hw = len < 2u ? 9u : hw;
+                // not a token of this round: no node, or the open match (finished by wave 0 below)
+                uint32_t w = hw + tw;
+                w = ext == kExtOpen ? 0u : w;
+                w = node[h] < 64u ? w : 0u;
+                const uint64_t v = w ? (((uint64_t)hv << tw) | tv) : 0ull;
+                valhi[h] = (uint32_t)(v >> 32); vallo[h] = (uint32_t)v; width[h] = w;
+                incl[h] = wave_inclusive_sum(w);
+                if (lane == 63u) L.chunk_bits[4 * h + wave] = incl[h];     // (exitfn is live: no dummy stores here)
+            }
+            PROF_STAMP(24);
             __syncthreads();
+            PROF_STAMP(25);
+            // bits of the chunks before mine: a scan over the 8 chunk sums in lanes 0..7
+            const uint32_t cbits = lane < 8u ? L.chunk_bits[lane & 7u] : 0u;
+            const uint32_t cincl = wave_inclusive_sum(cbits);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)cincl, 7);
+            const uint32_t cexcl = cincl - cbits;
+            const uint32_t at0 = wg_bit_at(o);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)cexcl, (int)(4 * h + wave));
+                const uint32_t at = (at0 + before + incl[h] - width[h]) & 8191u;
+                // OR the token (<= 33 bits), MSB first, at bit `at`; a lane without one ORs zeros
+                const uint64_t v = (((uint64_t)valhi[h] << 32) | vallo[h]) << ((64u - (at & 31u) - width[h]) & 63u);
+                // zeros go to a word of the thread's own: many lanes ORing into one word serialize
+                const uint32_t vh = (uint32_t)(v >> 32), vl = (uint32_t)v;
+                const uint32_t d = at >> 5;
+                const uint32_t dh = vh ? d : tid, dl = vl ? (d + 1u) & (kWgBitWords - 1) : tid;
+                __hip_atomic_fetch_or(&L.bits[dh], vh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&L.bits[dl], vl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            o.head += total;
+            PROF_STAMP(26);
 
             PROF_MARK(6);
             if (chain_end != kOpen) {
                 c = Pb + chain_end;                            // >= pend
             } else {
                 // ---- open match at Pb + open_at: wave 0 finishes it alone (:417-431)
+                __syncthreads();                               // every wave's bits of this round are in
                 if (wave == 0) {
                     const uint32_t off = L.res[(Pb + open_at) & (kWgResN - 1)] & kWindow;
                     if (lane == 0) {
@@ -1425,6 +1470,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         if (pending && c >= pend) { pending = false; W.resp = wg_dummy(L); }
     }
     if (wave == 0) { PROF_DONE; }
+    __syncthreads();                                           // the last round's bits are in
 
     // ---- end marker 1 1 0000000, zero pad to a byte, drain (:449-466)
     if (wave == 0) {

@@ -16,7 +16,7 @@ int main(int argc, char **argv)
     hipMalloc(&d_in, h.size()); hipMalloc(&d_out, (size_t)nb * stride); hipMalloc(&d_len, nb * 4);
     hipMemcpy(d_in, h.data(), h.size(), hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; rep++) {
-        unsigned long long zero[24] = {0};
+        unsigned long long zero[32] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(lzs_prof), zero, sizeof(zero));
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a);
@@ -24,7 +24,7 @@ int main(int argc, char **argv)
                            (const uint8_t *)d_in, (size_t)bl, (const uint32_t *)nullptr, bl, nb);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
-        unsigned long long p[24];
+        unsigned long long p[32];
         hipMemcpyFromSymbol(p, HIP_SYMBOL(lzs_prof), sizeof(p));
         const double nbytes = nb * 65536.0;
         double tot = 0; for (int i = 0; i < 8; i++) tot += (double)p[i];
@@ -35,6 +35,9 @@ int main(int argc, char **argv)
                (double)p[9] / p[13], (double)p[10] / p[13], (double)p[11] / p[13], (double)p[12] / (p[11] ? p[11] : 1));
         printf("  wave 0 search: cycles per refill pass %.0f, per step iteration %.0f\n", (double)p[14] / (p[9] ? p[9] : 1), (double)p[15] / (p[11] ? p[11] : 1));
         printf("  build: %.0f cycles per batch of 64 (%.2f batches per pool)\n", (double)p[16] / (p[17] ? p[17] : 1), (double)p[17] / p[13]);
+        { const double q = (double)p[13];
+          printf("  parse+pack cycles per pool: extend %.0f, doubling %.0f, barrier %.0f, exit walk %.0f, node+encode+scan %.0f, barrier %.0f, offsets+bits_or %.0f, barrier %.0f, stores %.0f, barrier %.0f\n",
+                 p[20] / q, p[21] / q, p[22] / q, p[23] / q, p[24] / q, p[25] / q, p[26] / q, p[27] / q, p[28] / q, p[29] / q); }
     }
     return 0;
 }
