@@ -861,6 +861,82 @@ template <class T> __device__ __forceinline__ T opaque(T x) { asm volatile("" : 
 // Where an idle lane's stores go: a word of its own in exitfn[], which is only live inside PARSE.
 __device__ __forceinline__ uint32_t *wg_dummy(BlkLds &L) { return reinterpret_cast<uint32_t *>(L.exitfn) + threadIdx.x; }
 
+// BUILD in two phases, so that the arithmetic is done once per position instead of once per wave.
+// HASH: the batches of [B0, Be) are dealt to the four waves; a wave computes, for each position
+// of its batches, both bucket numbers and whether the position is inserted at all (not inside a
+// run, gram within the input), and leaves them as a record in the result slot of that position
+// (free until SEARCH).  Whether a position is inside a run is read off ballots of "this byte
+// equals the next" over three neighbouring batches.
+// CHAIN (after a barrier): waves 0 and 1 keep the 3-byte chain, waves 2 and 3 the 2-byte chain,
+// each the buckets of one parity, so every bucket is chained by one wave's in-order instruction
+// stream.  No exec-masked regions and no branches inside the loops: a lane that must not insert
+// exchanges with its dummy word instead and its link goes there too; the link of a batch is
+// stored one iteration after its exchange was issued.  Same chains as wg_build64().
+__device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t n, uint32_t lane, uint32_t wave)
+{
+    const auto text4 = [&](uint32_t q) {
+        const uint32_t a = (q & kRingMask) >> 2;
+        return __builtin_amdgcn_alignbyte(L.ring[a + 1], L.ring[a], q);
+    };
+    // bit l: byte B+l equals byte B+l+1, and both are input
+    const auto eqnext = [&](uint32_t q, uint32_t t) {
+        const uint32_t diff = ((t ^ (t >> 8)) & 0xFFu) | (q + 1u < n ? 0u : 1u);
+        return __builtin_amdgcn_ballot_w64(diff == 0u);
+    };
+    // lane l needs the 13 bits from bit l-1 of (enext : ecur : eprev >> 63)
+    const bool first = lane == 0u, low = lane <= 32u;
+    const uint32_t shift = (lane + 31u) & 31u;
+    for (uint32_t B = B0 + 64u * wave; B < Be; B += 256u) {
+        const uint32_t p = B + lane;
+        const uint32_t tprev = text4(p - 64u), tcur = text4(p), tnext = text4(p + 64u);
+        const uint64_t eprev = B >= 64u ? eqnext(p - 64u, tprev) : 0ull;
+        const uint64_t ecur = eqnext(p, tcur), enext = eqnext(p + 64u, tnext);
+        const uint32_t w0 = (uint32_t)(eprev >> 32), w1 = (uint32_t)ecur, w2 = (uint32_t)(ecur >> 32), w3 = (uint32_t)enext;
+        const uint32_t lo = first ? w0 : (low ? w1 : w2), hi = first ? w1 : (low ? w2 : w3);
+        const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
+        // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
+        const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
+        const uint32_t h3 = ((tcur & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
+        const uint32_t h2 = (((tcur & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
+        const uint32_t out3 = skip | (p + 2u < n ? 0u : 1u), out2 = skip | (p + 1u < n ? 0u : 1u);
+        L.res[p & (kWgResN - 1)] = h3 | (h2 << 12) | (out3 << 24) | (out2 << 25);
+    }
+}
+
+__device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t lane, uint32_t wave)
+{
+    uint32_t *const dummy = wg_dummy(L);
+    uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
+    const bool two = wave >= 2u;                               // uniform
+    const uint32_t parity = wave & 1u;
+    uint32_t *const heads = two ? L.head2 : L.head3;
+    uint16_t *const links = two ? L.link2 : L.link3;
+    const uint32_t hshift = two ? 12u : 0u, oshift = two ? 25u : 24u;
+    // the exchange of the batch before, not yet turned into a link
+    uint32_t was = 0, was_p = 0, was_out = 1;
+    uint16_t *was_link = dummy16;
+    uint32_t rec = L.res[(B0 + lane) & (kWgResN - 1)];
+    for (uint32_t B = B0; B < Be; B += 64u) {
+        const uint32_t p = B + lane;
+        const uint32_t rec_next = L.res[(p + 64u) & (kWgResN - 1)];
+        const uint32_t h = (rec >> hshift) & 0xFFFu, out = (rec >> oshift) & 1u;
+        const uint32_t foreign = (h & 1u) ^ parity;
+        uint32_t *const ha = (foreign | out) == 0u ? &heads[h] : dummy;
+        const uint32_t old = __hip_atomic_exchange(ha, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint16_t *const la = foreign == 0u ? &links[wg_slot_base(B) + lane] : dummy16;
+        {
+            uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
+            d = was_out == 0u ? d : kNoLink;
+            *was_link = (uint16_t)d;
+        }
+        was = old; was_p = p; was_out = out; was_link = la;
+        rec = rec_next;
+    }
+    uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
+    d = was_out == 0u ? d : kNoLink;
+    *was_link = (uint16_t)d;
+}
+
 // BUILD for the batches [B0, Be) by one of the four waves, written for latency like the SEARCH
 // step.  Waves 0 and 1 keep the 3-byte chain, waves 2 and 3 the 2-byte chain, each the buckets of
 // one parity, so every bucket is still chained by one wave's in-order instruction stream.  No
@@ -1242,7 +1318,11 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             __syncthreads();
             PROF_MARK(0);
             // every wave walks all batches, inserting into its own buckets
-            { PROF_T0; PROF_COUNT(17, (Se - next) >> 6); wg_build_range(L, next, Se, n, lane, wave); PROF_T1(16); }
+            { PROF_T0; PROF_COUNT(17, (Se - next) >> 6);
+              wg_hash_range(L, next, Se, n, lane, wave);
+              __syncthreads();
+              wg_chain_range(L, next, Se, lane, wave);
+              PROF_T1(16); }
             next = Se;
         }
         const uint32_t send = Se < n ? Se : n;

@@ -1,0 +1,31 @@
+// Development probe: times the wg compress kernel of a given source snapshot (-DKSRC="\"file\"")
+// on the seeded workload, so that variants can be compared inside one gpurun call.
+#include KSRC
+#include <vector>
+extern "C" int lzs_workload_fill(uint8_t *, unsigned, uint64_t, uint64_t, size_t, size_t, int);
+int main(int argc, char **argv)
+{
+    const unsigned cls = argc > 1 ? atoi(argv[1]) : 0;
+    const uint32_t nb = argc > 2 ? atoi(argv[2]) : 16384, bl = 65536;
+    std::vector<uint8_t> h((size_t)nb * bl);
+    lzs_workload_fill(h.data(), cls, 0x4C5A5331ull, 0, nb, bl, 32);
+    uint8_t *d_in, *d_out; uint32_t *d_len;
+    const size_t stride = 73744;
+    hipMalloc(&d_in, h.size()); hipMalloc(&d_out, (size_t)nb * stride); hipMalloc(&d_len, nb * 4);
+    hipMemcpy(d_in, h.data(), h.size(), hipMemcpyHostToDevice);
+    float best = 1e9, sum = 0;
+    for (int rep = 0; rep < 7; rep++) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a);
+        hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nb), dim3(256), 0, 0, d_out, stride, 73731u, d_len,
+                           (const uint8_t *)d_in, (size_t)bl, (const uint32_t *)nullptr, bl, nb);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (rep >= 2) { sum += ms; if (ms < best) best = ms; }
+    }
+    std::vector<uint32_t> lens(nb);
+    hipMemcpy(lens.data(), d_len, nb * 4, hipMemcpyDeviceToHost);
+    unsigned long long tot = 0; for (auto v : lens) tot += v;
+    printf("class %u: mean %.3f ms best %.3f ms (%.2f GB/s), compressed bytes %llu\n", cls, sum / 5, best, nb * 65536.0 / (sum / 5) / 1e6, tot);
+    return 0;
+}
