@@ -886,55 +886,77 @@ __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t B
     // lane l needs the 13 bits from bit l-1 of (enext : ecur : eprev >> 63)
     const bool first = lane == 0u, low = lane <= 32u;
     const uint32_t shift = (lane + 31u) & 31u;
-    for (uint32_t B = B0 + 64u * wave; B < Be; B += 256u) {
-        const uint32_t p = B + lane;
-        const uint32_t tprev = text4(p - 64u), tcur = text4(p), tnext = text4(p + 64u);
-        const uint64_t eprev = B >= 64u ? eqnext(p - 64u, tprev) : 0ull;
-        const uint64_t ecur = eqnext(p, tcur), enext = eqnext(p + 64u, tnext);
-        const uint32_t w0 = (uint32_t)(eprev >> 32), w1 = (uint32_t)ecur, w2 = (uint32_t)(ecur >> 32), w3 = (uint32_t)enext;
-        const uint32_t lo = first ? w0 : (low ? w1 : w2), hi = first ? w1 : (low ? w2 : w3);
-        const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
-        // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
-        const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
-        const uint32_t h3 = ((tcur & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
-        const uint32_t h2 = (((tcur & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
-        const uint32_t out3 = skip | (p + 2u < n ? 0u : 1u), out2 = skip | (p + 1u < n ? 0u : 1u);
-        L.res[p & (kWgResN - 1)] = h3 | (h2 << 12) | (out3 << 24) | (out2 << 25);
+    // two batches of the wave side by side (straight-line code: their LDS reads overlap); one
+    // that lies past Be is computed all the same and stored to the dummy word
+    for (uint32_t B = B0 + 64u * wave; B < Be; B += 512u) {
+        uint32_t tprev[2], tcur[2], tnext[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t p = B + 256u * j + lane;
+            tprev[j] = text4(p - 64u); tcur[j] = text4(p); tnext[j] = text4(p + 64u);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t Bj = B + 256u * j, p = Bj + lane;
+            const uint64_t eprev = Bj >= 64u ? eqnext(p - 64u, tprev[j]) : 0ull;
+            const uint64_t ecur = eqnext(p, tcur[j]), enext = eqnext(p + 64u, tnext[j]);
+            const uint32_t w0 = (uint32_t)(eprev >> 32), w1 = (uint32_t)ecur, w2 = (uint32_t)(ecur >> 32), w3 = (uint32_t)enext;
+            const uint32_t lo = first ? w0 : (low ? w1 : w2), hi = first ? w1 : (low ? w2 : w3);
+            const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
+            // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
+            const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
+            const uint32_t h3 = ((tcur[j] & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
+            const uint32_t h2 = (((tcur[j] & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
+            const uint32_t out3 = skip | (p + 2u < n ? 0u : 1u), out2 = skip | (p + 1u < n ? 0u : 1u);
+            uint32_t *const to = Bj < Be ? &L.res[p & (kWgResN - 1)] : wg_dummy(L);
+            *to = h3 | (h2 << 12) | (out3 << 24) | (out2 << 25);
+        }
+    }
+}
+
+// CHAIN for `K` consecutive batches from B: all reads, then all exchanges, then all links, so the
+// LDS latencies are paid once per group.
+template <int K>
+__device__ __forceinline__ void wg_chain_group(BlkLds &L, uint32_t B, uint32_t &slot, uint32_t lane,
+                                               uint32_t *heads, uint16_t *links, uint32_t hshift, uint32_t oshift, uint32_t parity)
+{
+    uint32_t *const dummy = wg_dummy(L);
+    uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
+    uint32_t rec[K], old[K], out[K];
+    uint16_t *la[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) rec[j] = L.res[(B + 64u * j + lane) & (kWgResN - 1)];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint32_t p = B + 64u * j + lane;
+        const uint32_t h = (rec[j] >> hshift) & 0xFFFu;
+        out[j] = (rec[j] >> oshift) & 1u;
+        const uint32_t foreign = (h & 1u) ^ parity;
+        uint32_t *const ha = (foreign | out[j]) == 0u ? &heads[h] : dummy;
+        old[j] = __hip_atomic_exchange(ha, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        la[j] = foreign == 0u ? &links[slot + lane] : dummy16;
+        slot = slot + 64u >= kWgLinkN ? slot + 64u - kWgLinkN : slot + 64u;
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint32_t p = B + 64u * j + lane;
+        uint32_t d = p - old[j] < kNoLink ? p - old[j] : kNoLink;
+        d = out[j] == 0u ? d : kNoLink;
+        *la[j] = (uint16_t)d;
     }
 }
 
 __device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t lane, uint32_t wave)
 {
-    uint32_t *const dummy = wg_dummy(L);
-    uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
     const bool two = wave >= 2u;                               // uniform
     const uint32_t parity = wave & 1u;
     uint32_t *const heads = two ? L.head2 : L.head3;
     uint16_t *const links = two ? L.link2 : L.link3;
     const uint32_t hshift = two ? 12u : 0u, oshift = two ? 25u : 24u;
-    // the exchange of the batch before, not yet turned into a link
-    uint32_t was = 0, was_p = 0, was_out = 1;
-    uint16_t *was_link = dummy16;
-    uint32_t rec = L.res[(B0 + lane) & (kWgResN - 1)];
-    for (uint32_t B = B0; B < Be; B += 64u) {
-        const uint32_t p = B + lane;
-        const uint32_t rec_next = L.res[(p + 64u) & (kWgResN - 1)];
-        const uint32_t h = (rec >> hshift) & 0xFFFu, out = (rec >> oshift) & 1u;
-        const uint32_t foreign = (h & 1u) ^ parity;
-        uint32_t *const ha = (foreign | out) == 0u ? &heads[h] : dummy;
-        const uint32_t old = __hip_atomic_exchange(ha, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint16_t *const la = foreign == 0u ? &links[wg_slot_base(B) + lane] : dummy16;
-        {
-            uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
-            d = was_out == 0u ? d : kNoLink;
-            *was_link = (uint16_t)d;
-        }
-        was = old; was_p = p; was_out = out; was_link = la;
-        rec = rec_next;
-    }
-    uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
-    d = was_out == 0u ? d : kNoLink;
-    *was_link = (uint16_t)d;
+    uint32_t slot = wg_slot_base(B0);
+    uint32_t B = B0;
+    for (; B + 256u <= Be; B += 256u) wg_chain_group<4>(L, B, slot, lane, heads, links, hshift, oshift, parity);
+    for (; B < Be; B += 64u) wg_chain_group<1>(L, B, slot, lane, heads, links, hshift, oshift, parity);
 }
 
 // BUILD for the batches [B0, Be) by one of the four waves, written for latency like the SEARCH
