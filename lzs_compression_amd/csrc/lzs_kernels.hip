@@ -764,6 +764,11 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
 //           alone, 60 bytes per step.
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kWgThreads  = 256;
+// 3-byte buckets: as many as the LDS left over at five workgroups per CU holds (31.0 KB per workgroup
+// still fits five, 31.5 KB does not; not a power of
+// two: the hash is scaled into the range).  A quarter fewer collisions than 1024 buckets, and a
+// collision costs a whole SEARCH step.
+constexpr uint32_t kWgHead3    = 1256;
 constexpr uint32_t kWgPool     = 512;
 constexpr uint32_t kWgLinkN    = 3072;            // 48 x 64 >= 2047 + 2 * kWgPool: the pool in SEARCH and the one before
 constexpr uint32_t kWgResN     = 2 * kWgPool;     // results of two consecutive pools, by position & (kWgResN - 1)
@@ -777,7 +782,7 @@ constexpr uint32_t kExtMax     = 59;              // longest extension resolved 
 
 struct __attribute__((aligned(16))) BlkLds {
     uint32_t ring[kRingWords + 4];                // +16 B mirror of ring[0..15]
-    uint32_t head3[kHead3];
+    uint32_t head3[kWgHead3];
     uint32_t head2[kHead2];
     uint16_t link3[kWgLinkN];
     uint16_t link2[kWgLinkN];
@@ -791,6 +796,9 @@ struct __attribute__((aligned(16))) BlkLds {
     uint32_t pad[LZS_PAD_LDS / 4];                // occupancy experiments only
 #endif
 };
+
+// Bucket of the 3 bytes in the low 24 bits of t.
+__device__ __forceinline__ uint32_t wg_hash3(uint32_t t) { return __umulhi((t & 0xFFFFFFu) * 0x9E3779B1u, kWgHead3); }
 
 __device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) % (kWgLinkN / 64u)) * 64u; }
 
@@ -905,11 +913,11 @@ __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t B
             const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
             // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
             const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
-            const uint32_t h3 = ((tcur[j] & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
+            const uint32_t h3 = wg_hash3(tcur[j]);
             const uint32_t h2 = (((tcur[j] & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
             const uint32_t out3 = skip | (p + 2u < n ? 0u : 1u), out2 = skip | (p + 1u < n ? 0u : 1u);
             uint32_t *const to = Bj < Be ? &L.res[p & (kWgResN - 1)] : wg_dummy(L);
-            *to = h3 | (h2 << 12) | (out3 << 24) | (out2 << 25);
+            *to = h3 | (h2 << 11) | (out3 << 21) | (out2 << 22);
         }
     }
 }
@@ -918,7 +926,7 @@ __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t B
 // LDS latencies are paid once per group.
 template <int K>
 __device__ __forceinline__ void wg_chain_group(BlkLds &L, uint32_t B, uint32_t &slot, uint32_t lane,
-                                               uint32_t *heads, uint16_t *links, uint32_t hshift, uint32_t oshift, uint32_t parity)
+                                               uint32_t *heads, uint16_t *links, uint32_t hshift, uint32_t hmask, uint32_t oshift, uint32_t parity)
 {
     uint32_t *const dummy = wg_dummy(L);
     uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
@@ -929,7 +937,7 @@ __device__ __forceinline__ void wg_chain_group(BlkLds &L, uint32_t B, uint32_t &
 #pragma unroll
     for (int j = 0; j < K; j++) {
         const uint32_t p = B + 64u * j + lane;
-        const uint32_t h = (rec[j] >> hshift) & 0xFFFu;
+        const uint32_t h = (rec[j] >> hshift) & hmask;
         out[j] = (rec[j] >> oshift) & 1u;
         const uint32_t foreign = (h & 1u) ^ parity;
         uint32_t *const ha = (foreign | out[j]) == 0u ? &heads[h] : dummy;
@@ -952,79 +960,11 @@ __device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t 
     const uint32_t parity = wave & 1u;
     uint32_t *const heads = two ? L.head2 : L.head3;
     uint16_t *const links = two ? L.link2 : L.link3;
-    const uint32_t hshift = two ? 12u : 0u, oshift = two ? 25u : 24u;
+    const uint32_t hshift = two ? 11u : 0u, hmask = two ? 0x3FFu : 0x7FFu, oshift = two ? 22u : 21u;
     uint32_t slot = wg_slot_base(B0);
     uint32_t B = B0;
-    for (; B + 256u <= Be; B += 256u) wg_chain_group<4>(L, B, slot, lane, heads, links, hshift, oshift, parity);
-    for (; B < Be; B += 64u) wg_chain_group<1>(L, B, slot, lane, heads, links, hshift, oshift, parity);
-}
-
-// BUILD for the batches [B0, Be) by one of the four waves, written for latency like the SEARCH
-// step.  Waves 0 and 1 keep the 3-byte chain, waves 2 and 3 the 2-byte chain, each the buckets of
-// one parity, so every bucket is still chained by one wave's in-order instruction stream.  No
-// exec-masked regions and no branches inside the loop: a lane that must not insert (foreign
-// bucket, run interior, end of input) exchanges with its dummy word instead and its link goes
-// there too.  Whether a position is inside a run is read off ballots of "this byte equals the
-// next" over three neighbouring batches.  The text is read two batches ahead and the link of a
-// batch is stored one iteration after its exchange was issued, so LDS latency overlaps the
-// arithmetic.  Same chains as wg_build64().
-__device__ __forceinline__ void wg_build_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t n, uint32_t lane, uint32_t wave)
-{
-    uint32_t *const dummy = wg_dummy(L);
-    uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
-    const bool two = wave >= 2u;                               // uniform
-    const uint32_t parity = wave & 1u;
-    uint32_t *const heads = two ? L.head2 : L.head3;
-    uint16_t *const links = two ? L.link2 : L.link3;
-    const uint32_t tail = two ? 1u : 2u;                       // p + tail < n: the whole gram is input
-    const auto text4 = [&](uint32_t q) {
-        const uint32_t a = (q & kRingMask) >> 2;
-        return __builtin_amdgcn_alignbyte(L.ring[a + 1], L.ring[a], q);
-    };
-    // bit l: byte B+l equals byte B+l+1, and both are input
-    const auto eqnext = [&](uint32_t q, uint32_t t) {
-        const uint32_t diff = ((t ^ (t >> 8)) & 0xFFu) | (q + 1u < n ? 0u : 1u);
-        return __builtin_amdgcn_ballot_w64(diff == 0u);
-    };
-    uint64_t eprev = 0;
-    if (B0 >= 64u) eprev = eqnext(B0 - 64u + lane, text4(B0 - 64u + lane));
-    uint32_t tcur = text4(B0 + lane);
-    uint64_t ecur = eqnext(B0 + lane, tcur);
-    uint32_t tnext = text4(B0 + 64u + lane);
-    // lane l needs the 13 bits from bit l-1 of (enext : ecur : eprev >> 63)
-    const bool first = lane == 0u, low = lane <= 32u;
-    const uint32_t shift = (lane + 31u) & 31u;
-    // the exchange of the batch before, not yet turned into a link
-    uint32_t was = 0, was_p = 0, was_out = 1;
-    uint16_t *was_link = dummy16;
-    for (uint32_t B = B0; B < Be; B += 64u) {
-        const uint32_t p = B + lane;
-        const uint32_t tnext2 = text4(p + 128u);
-        const uint64_t enext = eqnext(p + 64u, tnext);
-        const uint32_t w0 = (uint32_t)(eprev >> 32), w1 = (uint32_t)ecur, w2 = (uint32_t)(ecur >> 32), w3 = (uint32_t)enext;
-        const uint32_t lo = first ? w0 : (low ? w1 : w2), hi = first ? w1 : (low ? w2 : w3);
-        const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
-        // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
-        const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
-        const uint32_t h3 = ((tcur & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
-        const uint32_t h2 = (((tcur & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
-        const uint32_t h = two ? h2 : h3;
-        const uint32_t foreign = (h & 1u) ^ parity;
-        const uint32_t out = opaque(skip | (p + tail < n ? 0u : 1u));
-        uint32_t *const ha = (foreign | out) == 0u ? &heads[h] : dummy;
-        const uint32_t old = __hip_atomic_exchange(ha, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint16_t *const la = foreign == 0u ? &links[wg_slot_base(B) + lane] : dummy16;
-        {
-            uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
-            d = was_out == 0u ? d : kNoLink;
-            *was_link = (uint16_t)d;
-        }
-        was = old; was_p = p; was_out = out; was_link = la;
-        eprev = ecur; ecur = enext; tcur = tnext; tnext = tnext2;
-    }
-    uint32_t d = was_p - was < kNoLink ? was_p - was : kNoLink;
-    d = was_out == 0u ? d : kNoLink;
-    *was_link = (uint16_t)d;
+    for (; B + 256u <= Be; B += 256u) wg_chain_group<4>(L, B, slot, lane, heads, links, hshift, hmask, oshift, parity);
+    for (; B < Be; B += 64u) wg_chain_group<1>(L, B, slot, lane, heads, links, hshift, hmask, oshift, parity);
 }
 
 // Insert the 64 positions starting at B.  `wave` < 4: only buckets owned by that wave
@@ -1049,7 +989,7 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
         deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
                p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
     }
-    const uint32_t h3 = ((t0 & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - LZS_HEAD3_BITS);
+    const uint32_t h3 = wg_hash3(t0);
     const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
     const uint32_t slot = wg_slot_base(B) + lane;
     if (wave == 4 || (h3 & 3u) == wave) {
@@ -1288,7 +1228,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     o.cap = out_cap;
     o.aligned4 = ((uintptr_t)o.dst & 3u) == 0;
 
-    for (uint32_t i = tid; i < kHead3; i += kWgThreads) L.head3[i] = ~0u;
+    for (uint32_t i = tid; i < kWgHead3; i += kWgThreads) L.head3[i] = ~0u;
     for (uint32_t i = tid; i < kHead2; i += kWgThreads) L.head2[i] = ~0u;
     L.bits[tid] = 0;
     __syncthreads();

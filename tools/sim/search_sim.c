@@ -15,7 +15,8 @@ static int use4 = 0;
 
 static uint32_t gram(const uint8_t *s, uint32_t p, uint32_t k, uint32_t n)
 { uint32_t g = 0; for (uint32_t i = 0; i < k; i++) g |= (uint32_t)(p + i < n ? s[p + i] : 0) << (8 * i); return g; }
-static uint32_t h3(uint32_t g) { return (g * 0x9E3779B1u) >> (32 - H3B); }
+static uint32_t H3N = 0;
+static uint32_t h3(uint32_t g) { return H3N ? (uint32_t)(((uint64_t)(g * 0x9E3779B1u) * H3N) >> 32) : (g * 0x9E3779B1u) >> (32 - H3B); }
 static uint32_t h2(uint32_t g) { return ((g * 40503u) >> 6) & ((1u << H2B) - 1); }
 static uint32_t h4(uint32_t g) { return (g * 0x9E3779B1u) >> (32 - H3B); }
 
@@ -23,6 +24,7 @@ static uint32_t lcp(const uint8_t *s, uint32_t a, uint32_t b, uint32_t lim)
 { uint32_t l = 0; while (l < lim && s[a + l] == s[b + l]) l++; return l; }
 
 /* steps[p] = step iterations position p occupies a lane for (0 = instant) */
+static uint16_t seg3[65536], seg2[65536];
 static void walks(const uint8_t *s, uint32_t n, uint16_t *steps, uint64_t *tot3, uint64_t *tot2)
 {
     uint32_t *head3 = malloc(4u << H3B), *head2 = malloc(4u << H2B), *head4 = malloc(4u << H3B);
@@ -44,7 +46,7 @@ static void walks(const uint8_t *s, uint32_t n, uint16_t *steps, uint64_t *tot3,
         const int walk3 = lim >= 3 && !capped && l3[p] <= reach;
         const int walk2 = lim >= 2 && !capped && !seeded && l2[p] <= reach;
         const int instant = !walk3 && !walk2 && !(seeded && len1 == CAP);
-        uint32_t st = 0;
+        uint32_t st = 0, st3 = 0;
         if (!instant) {
             int three = walk3, four = 0;
             uint32_t cum = 0, dist = walk3 ? l3[p] : (walk2 ? l2[p] : NOLINK);
@@ -62,12 +64,12 @@ static void walks(const uint8_t *s, uint32_t n, uint16_t *steps, uint64_t *tot3,
                     if (len > beat) { best = len; beat = len; if (use4 && three && !four && len >= 4) { four = 1; nd = l4[q]; } }
                 }
                 const int ended = !inwin || len >= stop;
-                if (ended && three && best < 2) { three = 0; four = 0; cum = 0; dist = walk2 ? l2[p] : NOLINK; beat = 1; stop = 2; if (!walk2) break; continue; }
+                if (ended && three && best < 2) { st3 = st; three = 0; four = 0; cum = 0; dist = walk2 ? l2[p] : NOLINK; beat = 1; stop = 2; if (!walk2) break; continue; }
                 if (ended) break;
                 cum = cum2; dist = nd;
             }
         }
-        steps[p] = (uint16_t)st;
+        steps[p] = (uint16_t)st; seg3[p] = (uint16_t)(st3 ? st3 : st); seg2[p] = (uint16_t)(st3 ? st - st3 : 0);
     }
     free(head3); free(head2); free(head4); free(l3); free(l2); free(l4);
 }
@@ -76,13 +78,14 @@ int main(int argc, char **argv)
 {
     const unsigned cls = argc > 1 ? atoi(argv[1]) : 0;
     const uint32_t nb = argc > 2 ? atoi(argv[2]) : 64, bl = 65536;
-    if (argc > 3) H3B = atoi(argv[3]);
+    if (argc > 3) { H3B = atoi(argv[3]); if (H3B > 20) { H3N = H3B; H3B = 11; } }
     if (argc > 4) H2B = atoi(argv[4]);
     const uint32_t refill_min = argc > 5 ? atoi(argv[5]) : 32;
     use4 = argc > 6 ? atoi(argv[6]) : 0;
     const int rolling = argc > 7 ? atoi(argv[7]) : 0;
     const uint32_t poolsz = argc > 8 ? atoi(argv[8]) : 512;
     const int halves = argc > 9 ? atoi(argv[9]) : 1;   /* walks per lane */
+    const int defer = argc > 10 ? atoi(argv[10]) : 0;  /* 2-byte chain restarts at the next refill pass */
     uint8_t *buf = malloc((size_t)nb * bl);
     lzs_workload_fill(buf, cls, 0x4C5A5331ull, 0, nb, bl, 8);
     uint16_t *steps = malloc(2 * bl);
@@ -96,8 +99,8 @@ int main(int argc, char **argv)
             hist[s == 0 ? 0 : s <= 2 ? 1 : s <= 4 ? 2 : s <= 8 ? 3 : s <= 16 ? 4 : s <= 32 ? 5 : s <= 64 ? 6 : 7] += s ? s : 1;
         }
         /* scheduling: 4 waves x 64 lanes, lock-step round robin over waves */
-        static uint32_t rem[4][256], own[4][256];
-        memset(rem, 0, sizeof rem);
+        static uint32_t rem[4][256], own[4][256], pend2[4][256];
+        memset(rem, 0, sizeof rem); memset(pend2, 0, sizeof pend2);
         uint32_t nextp = 0;
         const uint32_t pool = rolling == 1 ? bl : poolsz;
         const uint32_t lag = rolling >= 2 ? rolling - 1 : 0;
@@ -112,16 +115,23 @@ int main(int argc, char **argv)
                 for (int w = 0; w < 4; w++) {
                     if (done[w]) continue;
                     for (int h = 0; h < halves; h++) {
-                        uint32_t nidle = 0; for (int l = 64 * h; l < 64 * h + 64; l++) nidle += rem[w][l] == 0;
-                        if (!pool_done[w] && (nidle >= refill_min || nidle == 64)) {
-                            uint32_t basep = nextp; nextp += nidle; pool_done[w] = basep + nidle >= pend;
+                        uint32_t nidle = 0, npend = 0; for (int l = 64 * h; l < 64 * h + 64; l++) { nidle += rem[w][l] == 0; npend += rem[w][l] == 0 && pend2[w][l]; }
+                        if ((!pool_done[w] && (nidle >= refill_min || nidle == 64)) || (pool_done[w] && npend)) {
+                            uint32_t nnew = nidle - npend;
+                            uint32_t basep = nextp;
+                            if (!pool_done[w]) { nextp += nnew; pool_done[w] = basep + nnew >= pend; } else nnew = 0;
                             uint32_t r = 0;
-                            for (int l = 64 * h; l < 64 * h + 64; l++) if (rem[w][l] == 0) { uint32_t np = basep + r++; if (np < pend) { rem[w][l] = steps[np]; own[w][l] = k; } }
+                            for (int l = 64 * h; l < 64 * h + 64; l++) if (rem[w][l] == 0) {
+                                if (pend2[w][l]) { rem[w][l] = pend2[w][l]; pend2[w][l] = 0; continue; }
+                                if (!nnew) continue;
+                                uint32_t np = basep + r++;
+                                if (np < pend) { own[w][l] = k; if (defer) { rem[w][l] = seg3[np]; pend2[w][l] = seg2[np]; } else rem[w][l] = steps[np]; }
+                            }
                             passes++;
                         }
                     }
                     uint32_t nbusy = 0, nold = 0;
-                    for (int l = 0; l < 64 * halves; l++) { nbusy += rem[w][l] != 0; nold += rem[w][l] != 0 && (last || own[w][l] + lag <= k); }
+                    for (int l = 0; l < 64 * halves; l++) { nbusy += rem[w][l] != 0; nold += (rem[w][l] != 0 || pend2[w][l]) && (last || own[w][l] + lag <= k); }
                     if (pool_done[w] && nold == 0) { done[w] = 1; continue; }
                     if (nbusy == 0) continue;
                     iters++; busy_lane_steps += nbusy;
