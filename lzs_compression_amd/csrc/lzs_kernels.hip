@@ -1025,10 +1025,10 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         const uint32_t gi = 256u * h + 64u * wave + lane;
         if (64u * wave + 256u * h >= npos) continue;           // chunk past the end of the pool (uniform)
         const uint32_t p = Pb + gi;
-        // SEARCH stored (len << 16) | (0xFFFF - offset); offset 0 = no match
+        // SEARCH stored (len << 16) - offset; offset 0 = no match
         const uint32_t k = L.res[p & (kWgResN - 1)];
-        const uint32_t off = 0xFFFFu - (k & 0xFFFFu);
-        const uint32_t len = off ? k >> 16 : 0u;
+        const uint32_t off = (0u - k) & 0xFFFFu;
+        const uint32_t len = off ? (k + 0xFFFFu) >> 16 : 0u;
         const uint32_t r = off | (len << 11);
         // positions before the entry were not searched: what is stored there is stale
         const bool need = gi >= entry && gi < npos && len == kSearchCap && n - p > kSearchCap;
@@ -1076,18 +1076,18 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
 // a dummy word.
 struct Walk {
     uint32_t p, t0, t1, t2;      // position and its 12 bytes
-    uint32_t reach, myslot;      // window reach (<= 2047) and link slot of p
-    uint32_t cum, dist;          // distance walked so far, link to the next candidate
-    // best so far as (len << 16) | (0xFFFF - offset): candidates come nearest first, so a longer
-    // match wins and an equally long farther one does not.  0x2FFFF = "3-byte chain, nothing yet"
-    // (only a length >= 3 beats it), 0x1FFFF = "2-byte chain, nothing yet".
-    uint32_t key;
+    uint32_t nreach, myslot;     // ~(window reach): a distance d is inside iff -d > ~reach; link slot of p
+    uint32_t nback;              // MINUS the distance of the candidate to look at next
+    // best so far as (len << 16) - offset (signed compares): candidates come nearest first, so a
+    // longer match wins and an equally long farther one does not.  0x20000 = "3-byte chain, nothing
+    // yet" (only a length >= 3 beats it), 0x10000 = "2-byte chain, nothing yet".
+    int32_t key;
     uint32_t cap;                // length that ends the walk: min(remaining, 12), or 2 on the 2-byte chain
-    uint32_t first2;             // where the 2-byte chain starts (kNoLink: nowhere)
+    uint32_t nfirst2;            // MINUS the distance where the 2-byte chain starts (-kNoLink: nowhere)
     const uint16_t *links;       // link array being followed
     uint32_t *resp;              // where the result goes; the dummy word while the lane is idle
 };
-constexpr uint32_t kKeyNone3 = 0x2FFFFu, kKeyNone2 = 0x1FFFFu;
+constexpr int32_t kKeyNone3 = 0x20000, kKeyNone2 = 0x10000;
 
 // SEARCH: every wave pulls positions of [Pb, pend) from L.nextp.  A wave leaves when the pool has
 // no fresh position left and none of its lanes still walks for a position before Pb (those belong
@@ -1107,8 +1107,9 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
     const uint32_t slot0 = wg_slot_base(Pb);
     uint32_t *const dummy = wg_dummy(L);
     bool pool_done = false;
-    uint32_t p = W.p, t0 = W.t0, t1 = W.t1, t2 = W.t2, reach = W.reach, myslot = W.myslot;
-    uint32_t cum = W.cum, dist = W.dist, key = W.key, cap = W.cap, first2 = W.first2;
+    uint32_t p = W.p, t0 = W.t0, t1 = W.t1, t2 = W.t2, nreach = W.nreach, myslot = W.myslot;
+    uint32_t nback = W.nback, cap = W.cap, nfirst2 = W.nfirst2;
+    int32_t key = W.key;
     const uint16_t *links = W.links;
     uint32_t *resp = W.resp;
     for (;;) {
@@ -1146,20 +1147,20 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
                 }
                 const bool seeded = maybe1 && len1 >= 2u;
                 const bool capped = seeded && len1 == lim;               // nothing nearer or longer exists
-                reach = p < kWindow ? p : kWindow;
+                const uint32_t reach = p < kWindow ? p : kWindow;
+                nreach = ~reach;
                 // chains that are empty inside the window are skipped here, not discovered by a step
                 const bool walk3 = lim >= 3u && !capped && l3 <= reach;
                 const bool walk2 = lim >= 2u && !capped && !seeded && l2 <= reach;
-                first2 = walk2 ? l2 : kNoLink;
-                dist = walk3 ? l3 : first2;
-                cum = 0u;
+                nfirst2 = 0u - (walk2 ? l2 : kNoLink);
+                nback = walk3 ? 0u - l3 : nfirst2;
                 // 3-byte chain: only a longer match than the seed (or than 2) counts and the cap ends
                 // the walk (:337-345); 2-byte chain: the first verified candidate is the answer
-                key = seeded ? ((len1 << 16) | 0xFFFEu) : (walk3 ? kKeyNone3 : kKeyNone2);
+                key = seeded ? (int32_t)((len1 << 16) - 1u) : (walk3 ? kKeyNone3 : kKeyNone2);
                 cap = walk3 ? lim : 2u;
                 links = walk3 ? L.link3 : L.link2;
                 uint32_t *const slot = &L.res[p & (kWgResN - 1)];
-                *slot = key;                                             // final if there is no chain to walk
+                *slot = (uint32_t)key;                                   // final if there is no chain to walk
                 resp = (walk3 || walk2) ? slot : dummy;
             }
             PROF_T1(14);
@@ -1171,35 +1172,33 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
 #pragma unroll
         for (int sub = 0; sub < LZS_SUBSTEPS; sub++) {
             // One step = one candidate, for all 64 lanes alike.
-            const uint32_t cum2 = cum + dist;
-            const bool inwin = cum2 <= reach;
-            const uint32_t back = inwin ? cum2 : 0u;          // out of the window: look at p itself ...
+            const bool inwin = nback > nreach;
+            const uint32_t nb = inwin ? nback : 0u;           // out of the window: look at p itself ...
             const uint32_t capx = inwin ? cap : 0u;           // ... and count none of it
             uint32_t w0, w1, w2;
-            ringm_read12(L.ring, p - back, w0, w1, w2);
-            const uint32_t at = myslot - back;
+            ringm_read12(L.ring, p + nb, w0, w1, w2);
+            const uint32_t at = myslot + nb;
             const uint32_t nd = links[at < at + kWgLinkN ? at : at + kWgLinkN];
             uint32_t len = lcp12(w0 ^ t0, w1 ^ t1, w2 ^ t2);
             len = len < capx ? len : capx;
-            const uint32_t cand = (len << 16) | (0xFFFFu - back);
+            const int32_t cand = (int32_t)((len << 16) + nb);
             key = key > cand ? key : cand;
-            *resp = key;
+            *resp = (uint32_t)key;
             // the walk ends at the cap, or where the chain leaves the window (capx = 0 = len)
-            const uint32_t kend = opaque(len == capx ? key : 0u);
+            const int32_t kend = opaque(len == capx ? key : 0);
             // nothing on the 3-byte chain: restart on the 2-byte chain
             const bool fallback = kend == kKeyNone3;
-            const uint32_t kfin = opaque(fallback ? 0u : kend);
+            const int32_t kfin = opaque(fallback ? 0 : kend);
             key = fallback ? kKeyNone2 : key;
             cap = fallback ? 2u : cap;
-            cum = fallback ? 0u : cum2;
-            dist = fallback ? first2 : nd;
+            nback = fallback ? nfirst2 : nback - nd;
             links = fallback ? L.link2 : links;
-            resp = kfin != 0u ? dummy : resp;                  // ended for good: the lane is idle
+            resp = kfin != 0 ? dummy : resp;                   // ended for good: the lane is idle
         }
         PROF_T1B(15);
     }
-    W.p = p; W.t0 = t0; W.t1 = t1; W.t2 = t2; W.reach = reach; W.myslot = myslot;
-    W.cum = cum; W.dist = dist; W.key = key; W.cap = cap; W.first2 = first2;
+    W.p = p; W.t0 = t0; W.t1 = t1; W.t2 = t2; W.nreach = nreach; W.myslot = myslot;
+    W.nback = nback; W.key = key; W.cap = cap; W.nfirst2 = nfirst2;
     W.links = links; W.resp = resp;
 }
 
@@ -1241,8 +1240,8 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     // The pools are pipelined: while pool k is in SEARCH, pool k-1 (searched in the round before,
     // except for the walks carried over, which end in this round's SEARCH) waits for PARSE + PACK.
     Walk W;
-    W.p = 0; W.t0 = W.t1 = W.t2 = 0; W.reach = 0; W.myslot = 0;
-    W.cum = 0; W.dist = kNoLink; W.key = 0; W.cap = 0; W.first2 = kNoLink;
+    W.p = 0; W.t0 = W.t1 = W.t2 = 0; W.nreach = ~0u; W.myslot = 0;
+    W.nback = 0u - kNoLink; W.key = 0; W.cap = 0; W.nfirst2 = 0u - kNoLink;
     W.links = L.link2; W.resp = wg_dummy(L);
     bool pending = false;                    // a searched pool waits for PARSE
     uint32_t Pb = 0, pend = 0;               // that pool
