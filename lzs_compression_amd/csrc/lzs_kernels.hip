@@ -806,11 +806,14 @@ __device__ __forceinline__ uint32_t wg_slot_base(uint32_t B) { return ((B >> 6) 
 // 12 or more (a large number) when all are equal -- callers clamp to their own limit.
 __device__ __forceinline__ uint32_t lcp12(uint32_t x0, uint32_t x1, uint32_t x2)
 {
-    const uint32_t tail = x1 ? x1 : x2, tail_at = x1 ? 4u : 8u;
-    const uint32_t word = x0 ? x0 : tail, at = x0 ? 0u : tail_at;     // first word that differs
-    uint32_t low;                                                      // v_ffbl_b32: -1 for 0
-    asm("v_ffbl_b32 %0, %1" : "=v"(low) : "v"(word));
-    return at + (low >> 3);                                            // word == 0 -> huge
+    // v_ffbl_b32 gives -1 for 0, which survives the OR: the first set bit of x2:x1:x0, or huge
+    uint32_t f0, f1, f2;
+    asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(x0));
+    asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(x1));
+    asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(x2));
+    const uint32_t a = f1 | 32u, b = f2 | 64u;
+    const uint32_t m = f0 < a ? (f0 < b ? f0 : b) : (a < b ? a : b);   // v_min3_u32
+    return m >> 3;                                                      // all equal -> huge
 }
 
 // OR `width` (1..32) bits of `value`, MSB first, at bit offset `at` of a ring of `words` words.
@@ -875,11 +878,11 @@ __device__ __forceinline__ uint32_t *wg_dummy(BlkLds &L) { return reinterpret_ca
 // run, gram within the input), and leaves them as a record in the result slot of that position
 // (free until SEARCH).  Whether a position is inside a run is read off ballots of "this byte
 // equals the next" over three neighbouring batches.
-// CHAIN (after a barrier): waves 0 and 1 keep the 3-byte chain, waves 2 and 3 the 2-byte chain,
-// each the buckets of one parity, so every bucket is chained by one wave's in-order instruction
-// stream.  No exec-masked regions and no branches inside the loops: a lane that must not insert
-// exchanges with its dummy word instead and its link goes there too; the link of a batch is
-// stored one iteration after its exchange was issued.  Same chains as wg_build64().
+// CHAIN (after a barrier): wave 0 keeps the 3-byte chain and wave 1 the 2-byte chain, so every
+// bucket is chained by one wave's in-order instruction stream; waves 2 and 3 wait (the kernel is
+// bound by VALU issue, and chaining four ways only repeated the record decoding).  No
+// exec-masked regions and no branches inside the loops: a lane that must not insert exchanges
+// with its dummy word instead.  Same chains as wg_build64().
 __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t n, uint32_t lane, uint32_t wave)
 {
     const auto text4 = [&](uint32_t q) {
@@ -926,10 +929,9 @@ __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t B
 // LDS latencies are paid once per group.
 template <int K>
 __device__ __forceinline__ void wg_chain_group(BlkLds &L, uint32_t B, uint32_t &slot, uint32_t lane,
-                                               uint32_t *heads, uint16_t *links, uint32_t hshift, uint32_t hmask, uint32_t oshift, uint32_t parity)
+                                               uint32_t *heads, uint16_t *links, uint32_t hshift, uint32_t hmask, uint32_t oshift)
 {
     uint32_t *const dummy = wg_dummy(L);
-    uint16_t *const dummy16 = reinterpret_cast<uint16_t *>(dummy);
     uint32_t rec[K], old[K], out[K];
     uint16_t *la[K];
 #pragma unroll
@@ -939,10 +941,9 @@ __device__ __forceinline__ void wg_chain_group(BlkLds &L, uint32_t B, uint32_t &
         const uint32_t p = B + 64u * j + lane;
         const uint32_t h = (rec[j] >> hshift) & hmask;
         out[j] = (rec[j] >> oshift) & 1u;
-        const uint32_t foreign = (h & 1u) ^ parity;
-        uint32_t *const ha = (foreign | out[j]) == 0u ? &heads[h] : dummy;
+        uint32_t *const ha = out[j] == 0u ? &heads[h] : dummy;
         old[j] = __hip_atomic_exchange(ha, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        la[j] = foreign == 0u ? &links[slot + lane] : dummy16;
+        la[j] = &links[slot + lane];
         slot = slot + 64u >= kWgLinkN ? slot + 64u - kWgLinkN : slot + 64u;
     }
 #pragma unroll
@@ -956,15 +957,15 @@ __device__ __forceinline__ void wg_chain_group(BlkLds &L, uint32_t B, uint32_t &
 
 __device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t lane, uint32_t wave)
 {
-    const bool two = wave >= 2u;                               // uniform
-    const uint32_t parity = wave & 1u;
+    if (wave >= 2u) return;                                    // waves 2 and 3 only wait: the kernel is VALU-bound
+    const bool two = wave == 1u;                               // uniform
     uint32_t *const heads = two ? L.head2 : L.head3;
     uint16_t *const links = two ? L.link2 : L.link3;
     const uint32_t hshift = two ? 11u : 0u, hmask = two ? 0x3FFu : 0x7FFu, oshift = two ? 22u : 21u;
     uint32_t slot = wg_slot_base(B0);
     uint32_t B = B0;
-    for (; B + 256u <= Be; B += 256u) wg_chain_group<4>(L, B, slot, lane, heads, links, hshift, hmask, oshift, parity);
-    for (; B < Be; B += 64u) wg_chain_group<1>(L, B, slot, lane, heads, links, hshift, hmask, oshift, parity);
+    for (; B + 256u <= Be; B += 256u) wg_chain_group<4>(L, B, slot, lane, heads, links, hshift, hmask, oshift);
+    for (; B < Be; B += 64u) wg_chain_group<1>(L, B, slot, lane, heads, links, hshift, hmask, oshift);
 }
 
 // Insert the 64 positions starting at B.  `wave` < 4: only buckets owned by that wave
