@@ -1367,17 +1367,15 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                 o.head -= 2048u;
             }
             // follow the published exits from the entry, one hop per chunk, in every lane alike
+            // (on the scalar unit: the kernel is VALU-bound, and this walk is the same in all four waves)
             uint32_t node[2] = {0x100u, 0x100u};
-            uint32_t pos = entry;
-#pragma unroll
-            for (int hop = 0; hop < 8; hop++) {
-                const uint32_t k = pos < npos ? pos >> 6 : 0xFFu;
-                node[0] = k == wave ? pos & 63u : node[0];
-                node[1] = k == wave + 4u ? pos & 63u : node[1];
-                const uint32_t nx = L.exitfn[pos < kWgPool ? pos : kWgPool - 1u];
-                pos = k != 0xFFu ? nx : pos;
+            uint32_t last = entry;
+            while (last < npos) {
+                const uint32_t k = last >> 6;
+                if (k == wave) node[0] = last & 63u;
+                if (k == wave + 4u) node[1] = last & 63u;
+                last = uniform((uint32_t)L.exitfn[last]);
             }
-            const uint32_t last = uniform(pos);
             const uint32_t chain_end = (last & 0x8000u) ? kOpen : last;
             const uint32_t open_at = last & 0x7FFFu;
             PROF_STAMP(23);
