@@ -61,11 +61,14 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 }
 
 // 16 input bytes at block position p (multiple of 16), zero past n.
-__device__ __forceinline__ uint4 load16(const uint8_t *src, uint32_t p, uint32_t n, bool aligned16)
+__device__ __forceinline__ uint4 load16(const uint8_t *src, uint32_t p, uint32_t n, bool aligned16, bool aligned4 = false)
 {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (p + 16 <= n && aligned16) {
         v = *reinterpret_cast<const uint4 *>(src + p);
+    } else if (p + 16 <= n && aligned4) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(src + p);
+        v = make_uint4(w[0], w[1], w[2], w[3]);
     } else if (p < n) {
         uint32_t w[4] = {0, 0, 0, 0};
         uint32_t m = n - p < 16 ? n - p : 16;
@@ -481,11 +484,10 @@ __device__ __forceinline__ void ringm_read12(const uint32_t *ring, uint32_t q,
                                              uint32_t &w0, uint32_t &w1, uint32_t &w2)
 {
     const uint32_t a = (q & kRingMask) >> 2;     // words a..a+3 exist thanks to the mirror
-    const uint32_t s = q & 3;
     const uint32_t d0 = ring[a], d1 = ring[a + 1], d2 = ring[a + 2], d3 = ring[a + 3];
-    w0 = __builtin_amdgcn_alignbyte(d1, d0, s);
-    w1 = __builtin_amdgcn_alignbyte(d2, d1, s);
-    w2 = __builtin_amdgcn_alignbyte(d3, d2, s);
+    w0 = __builtin_amdgcn_alignbyte(d1, d0, q);  // v_alignbyte_b32 shifts by the low two bits of q
+    w1 = __builtin_amdgcn_alignbyte(d2, d1, q);
+    w2 = __builtin_amdgcn_alignbyte(d3, d2, q);
 }
 
 __device__ __forceinline__ void chain_refill(ChainLds &L, const uint8_t *src, uint32_t n, bool src16,
@@ -1262,18 +1264,14 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             // back from the pool before, and the ring holds 4096.
             const uint32_t need = (Se > c ? Se : c) + 96;
             while (loaded < n && loaded < need) {
-                const uint32_t p = loaded + 4 * tid;
-                if (tid < 128) {
-                    uint32_t v = 0;
-                    if (p + 4 <= n && src4) {
-                        v = *reinterpret_cast<const uint32_t *>(src + p);
-                    } else {
-                        for (uint32_t k = 0; k < 4; k++)
-                            if (p + k < n) v |= (uint32_t)src[p + k] << (8 * k);
-                    }
+                // half a KiB by 32 lanes of one wave (the waves take turns): the kernel is bound
+                // by VALU issue, and four waves computing addresses for 4 bytes each cost four times this
+                if (wave == ((loaded >> 9) & 3u) && lane < 32u) {
+                    const uint32_t p = loaded + 16 * lane;
+                    const uint4 v = load16(src, p, n, src16, src4);
                     const uint32_t at = (p & kRingMask) >> 2;
-                    L.ring[at] = v;
-                    if (at < 4) L.ring[kRingWords + at] = v;
+                    *reinterpret_cast<uint4 *>(&L.ring[at]) = v;
+                    if (at == 0) *reinterpret_cast<uint4 *>(&L.ring[kRingWords]) = v;
                 }
                 loaded += kTile / 2;
             }
