@@ -1020,12 +1020,14 @@ __device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, ui
 // position, so only the first of each such run (per 64-position chunk) compares bytes -- up to
 // kTokenMax + kExtMax + 1 of them -- and the others derive theirs.  Beyond that the match is
 // "open" (finished serially in PARSE), and so is everything derived from an open one.
-__device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry, uint32_t npos, uint32_t n, uint32_t lane, uint32_t wave)
+__device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry, uint32_t npos, uint32_t n, uint32_t lane, uint32_t wave,
+                                          uint32_t (&rr)[2])
 {
     constexpr uint32_t kRoom = kTokenMax + kExtMax + 1;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t gi = 256u * h + 64u * wave + lane;
+        rr[h] = 0;
         if (64u * wave + 256u * h >= npos) continue;           // chunk past the end of the pool (uniform)
         const uint32_t p = Pb + gi;
         // SEARCH stored (len << 16) - offset; offset 0 = no match
@@ -1037,7 +1039,7 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         const bool need = gi >= entry && gi < npos && len == kSearchCap && n - p > kSearchCap;
         const uint64_t needs = __builtin_amdgcn_ballot_w64(need);
         if (needs == 0ull) {
-            L.res[p & (kWgResN - 1)] = r | ((len > kTokenMax ? len - kTokenMax : 0u) << 15);
+            rr[h] = r | ((len > kTokenMax ? len - kTokenMax : 0u) << 15);
             continue;
         }
         const uint32_t left = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane - 1u) << 2), (int)r);
@@ -1062,7 +1064,7 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         const uint32_t th = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hp << 2), (int)total);
         uint32_t ext = len >= kTokenMax ? len - kTokenMax : 0u;
         if (need) ext = th >= kRoom ? kExtOpen : th - (lane - hp) - kTokenMax;
-        L.res[p & (kWgResN - 1)] = r | (ext << 15);
+        rr[h] = r | (ext << 15);
     }
 }
 
@@ -1311,19 +1313,20 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
         // token order and the bit offsets are a prefix sum.
         const uint32_t npos = pend - Pb;
         PROF_STAMP0;
-        wg_extend(L, Pb, c - Pb, npos, n, lane, wave);                 // each thread completes the results it reads below
+        uint32_t rr[2];                                        // results of this thread's two positions, complete
+        wg_extend(L, Pb, c - Pb, npos, n, lane, wave, rr);
         PROF_STAMP(20);
         while (c < pend && o.flushed < o.cap) {
             const uint32_t entry = c - Pb;
             // Written for latency (see Walk): the two chunks of a wave go through every
             // dependent cross-lane step side by side, predicates are single compares consumed
             // by selects, and nothing is exec-masked.
-            uint32_t rr[2], T[2][6], t[2];
+            uint32_t T[2][6], t[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t cb = 256u * h + 64u * wave;                 // pool-relative start of the chunk
                 const uint32_t inside = cb < npos ? (npos - cb < 64u ? npos - cb : 64u) : 0u;   // its positions in the pool
-                const uint32_t r = L.res[(Pb + cb + lane) & (kWgResN - 1)];
+                const uint32_t r = rr[h];
                 const uint32_t len = (r >> 11) & 15u, ext = r >> 15;
                 uint32_t step = len < kTokenMax ? len : kTokenMax + ext;
                 step = len < 2u ? 1u : step;
@@ -1333,7 +1336,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                 uint32_t x = land < inside ? land : (0x100u | land);
                 x = ext == kExtOpen ? (0x200u | lane) : x;                 // ext is 63 only for an open match
                 x = lane < inside ? x : (0x100u | lane);
-                rr[h] = r; t[h] = x;
+                t[h] = x;
             }
 #pragma unroll
             for (int d = 0; d < 6; d++) {
@@ -1341,7 +1344,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     T[h][d] = t[h];
-                    via[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((t[h] & 63u) << 2), (int)t[h]);
+                    via[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t[h] << 2), (int)t[h]);
                 }
 #pragma unroll
                 for (int h = 0; h < 2; h++) t[h] = t[h] < 64u ? via[h] : t[h];
@@ -1384,7 +1387,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                 uint32_t via[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    via[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node[h] & 63u) << 2), (int)T[h][d]);
+                    via[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(node[h] << 2), (int)T[h][d]);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const uint32_t on = node[h] < 64u ? via[h] : node[h];
@@ -1394,7 +1397,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             uint32_t valhi[2], vallo[2], width[2], incl[2], rtok[2], btok[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                rtok[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((node[h] & 63u) << 2), (int)rr[h]);
+                rtok[h] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(node[h] << 2), (int)rr[h]);
                 btok[h] = ring_byte(L.ring, Pb + 256u * h + 64u * wave + (node[h] & 63u)) & 0xFFu;
             }
 #pragma unroll
@@ -1456,7 +1459,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                 // ---- open match at Pb + open_at: wave 0 finishes it alone (:417-431)
                 __syncthreads();                               // every wave's bits of this round are in
                 if (wave == 0) {
-                    const uint32_t off = L.res[(Pb + open_at) & (kWgResN - 1)] & kWindow;
+                    const uint32_t off = (0u - L.res[(Pb + open_at) & (kWgResN - 1)]) & kWindow;   // raw key: (len << 16) - offset
                     if (lane == 0) {
                         if (off <= kShortMax) bits_or(L.bits, kWgBitWords, wg_bit_at(o), (((3u << 7) | off) << 4) | 0xFu, 13);
                         else                  bits_or(L.bits, kWgBitWords, wg_bit_at(o), (((2u << 11) | off) << 4) | 0xFu, 17);

@@ -85,7 +85,8 @@ int main(int argc, char **argv)
     const int rolling = argc > 7 ? atoi(argv[7]) : 0;
     const uint32_t poolsz = argc > 8 ? atoi(argv[8]) : 512;
     const int halves = argc > 9 ? atoi(argv[9]) : 1;   /* walks per lane */
-    const int defer = argc > 10 ? atoi(argv[10]) : 0;  /* 2-byte chain restarts at the next refill pass */
+    const int defer = argc > 10 ? atoi(argv[10]) : 0;
+    const int per = argc > 11 ? atoi(argv[11]) : 1;   /* candidates per step */  /* 2-byte chain restarts at the next refill pass */
     uint8_t *buf = malloc((size_t)nb * bl);
     lzs_workload_fill(buf, cls, 0x4C5A5331ull, 0, nb, bl, 8);
     uint16_t *steps = malloc(2 * bl);
@@ -93,6 +94,7 @@ int main(int argc, char **argv)
     uint64_t hist[8] = {0}, maxsum = 0;
     for (uint32_t b = 0; b < nb; b++) {
         walks(buf + (size_t)b * bl, bl, steps, &tot3, &tot2);
+        if (per > 1) for (uint32_t p = 0; p < bl; p++) { steps[p] = (steps[p] + per - 1) / per; }
         for (uint32_t p = 0; p < bl; p++) {
             totsteps += steps[p]; npos++; ninst += steps[p] == 0;
             const uint32_t s = steps[p];
