@@ -208,6 +208,39 @@ def test_fuzz_ragged_batch_vs_oracle():
     assert backs == datas
 
 
+def test_long_matches_across_chunk_and_pool_boundaries():
+    """Matches that fill the 12-byte search cap and run on: exact totals around the limits of the
+    in-kernel extension (8 + 59, then "open"), starting at every alignment to the 64-position
+    chunks and the 512-position pools, alone, back to back and nested in runs (the pass that
+    completes them derives most lengths from a neighbour instead of comparing bytes)."""
+    rng = np.random.default_rng(4242)
+    datas = []
+    for total in (12, 13, 14, 19, 20, 23, 24, 27, 66, 67, 68, 69, 70, 127, 128, 300, 700):
+        for _ in range(12):
+            lead = int(rng.integers(0, 1100))
+            gap = int(rng.integers(0, 1900))
+            phrase = bytes(rng.integers(0, 256, total, dtype=np.uint8))
+            a = bytes(rng.integers(0, 256, lead, dtype=np.uint8))
+            g = bytes(rng.integers(0, 256, gap, dtype=np.uint8))
+            tail = bytes(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8))
+            datas.append(a + phrase + g + phrase + tail)
+            # the same phrase three times: nested candidates at two offsets
+            datas.append(a + phrase + g[: gap // 2] + phrase + g[gap // 2:] + phrase[: total - 1] + tail)
+            # a match that ends exactly at the end of the input
+            datas.append(a + phrase + g + phrase)
+    # runs of one byte and of short periods whose ends fall around every chunk boundary
+    for period in (1, 2, 3, 16, 63, 64, 65):
+        for _ in range(10):
+            lead = int(rng.integers(0, 700))
+            run = int(rng.integers(13, 2600))
+            unit = bytes(rng.integers(0, 256, period, dtype=np.uint8))
+            a = bytes(rng.integers(0, 256, lead, dtype=np.uint8))
+            datas.append(a + (unit * (run // period + 1))[:run] + bytes(rng.integers(0, 256, 30, dtype=np.uint8)))
+    comps = _gpu_compress_many(datas)
+    for d, c in zip(datas, comps):
+        assert c == O.compress(d)
+
+
 def test_fuzz_decoder_on_garbage_vs_oracle():
     rng = np.random.default_rng(77)
     streams = [bytes(rng.integers(0, 256, int(rng.integers(0, 400)), dtype=np.uint8)) for _ in range(300)]
