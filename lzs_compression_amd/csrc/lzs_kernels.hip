@@ -1716,6 +1716,171 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
 }
 
 // ---------------------------------------------------------------------------------
+// lzs_decompress() per block, second version (the default).  Same rules, same wave-per-stream
+// shape; what changed is where the instructions go.  The first version spent 29 scalar
+// instructions per output byte and saturated the CU's one scalar unit (rocprofv3: 3.1e10 SALU per
+// GiB = 93 % of its issue slots) -- its compressed input went HBM -> LDS tile -> ds_read ->
+// v_readfirstlane, and its conditions were combined as lane masks.  Here the compressed stream is
+// read straight into scalar registers (s_load_dword, one word ahead of use, no LDS tile), and the
+// token decode is nested single compares.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWavesPerWG * 64)
+void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
+                                     uint32_t *__restrict__ out_len,
+                                     const uint8_t *__restrict__ in, size_t in_stride,
+                                     const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
+                                     uint32_t nblocks, uint32_t concat)
+{
+    __shared__ uint32_t rings[kWavesPerWG][kRingWords];           // the OUTPUT's sliding window
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv   = uniform(threadIdx.x >> 6);
+    const uint32_t b    = blockIdx.x * kWavesPerWG + wv;
+    if (b >= nblocks) return;
+
+    uint32_t *ring = rings[wv];
+    uint8_t *ring8 = reinterpret_cast<uint8_t *>(ring);
+    const uint8_t *src = in + (size_t)b * in_stride;
+    const uint32_t n   = uniform(in_len ? in_len[b] : in_len_uniform);
+    uint8_t *dst       = out + (size_t)b * out_stride;
+    const bool dst16   = ((uintptr_t)dst & 15u) == 0;
+    const uint32_t cap = out_cap;
+
+    // ---- the input as aligned words: word j holds stream bytes [4j - skew, 4j - skew + 4)
+    const uint32_t skew = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(src - skew);
+    const uint32_t nwords = n ? (skew + n + 3u) >> 2 : 0u;         // words that hold stream bytes
+    uint64_t bits = 0;        // left-aligned bit buffer
+    uint32_t have = 0;        // valid bits in `bits`
+    uint32_t pos  = 0;        // stream bytes fed so far
+    uint32_t wi   = 0;        // next word to feed
+    uint32_t nextw = 0;       // that word, loaded ahead of use
+    if (nwords) {
+        uint32_t w = __builtin_bswap32(w32[0]) << (8u * skew);
+        const uint32_t avail = 4u - skew < n ? 4u - skew : n;
+        if (avail < 4u) w &= ~0u << (32u - 8u * avail);
+        bits = (uint64_t)w << 32;
+        have = 8u * avail;
+        pos = avail;
+        wi = 1;
+        if (nwords > 1u) nextw = w32[1];
+    }
+    uint32_t count = 0;       // bytes produced
+    uint32_t flushed = 0;     // bytes stored to HBM (multiple of kTile)
+    uint32_t off = 0;
+    uint32_t extended = 0;
+
+    for (;;) {
+        // ---- refill (lzs-decompression.c:181-187).  One word per token is enough: no token path
+        // below takes more than 32 bits except a run of literals, which takes what is there.
+        if (have <= 32u) {
+            if (pos < n) {
+                uint32_t w = __builtin_bswap32(nextw);
+                const uint32_t rem = n - pos;
+                const uint32_t nb = rem < 4u ? rem : 4u;           // bytes that really exist
+                if (rem < 4u) w &= ~0u << (32u - 8u * rem);
+                bits |= (uint64_t)w << (32u - have);
+                have += 8u * nb;
+                pos += nb;
+                wi += 1u;
+                if (wi < nwords) nextw = w32[wi];
+            }
+        }
+        if (have == 0u) break;                                     // :189
+        if (count >= cap) break;                                   // :200, and mid-copy :361-364
+        const uint32_t room = cap - count;
+
+        uint32_t copy_len = 0;
+        const uint32_t top = (uint32_t)(bits >> 32);
+        if (extended) {                                            // :370-406
+            if (have < 4u) break;
+            const uint32_t e = top >> 28;
+            bits <<= 4; have -= 4u;
+            copy_len = e;
+            extended = e == kNibbleMax ? 1u : 0u;
+        } else if ((int32_t)top >= 0) {
+            // a run of literals (:217-233), up to 7 at once: token i of an all-literal run starts
+            // at bit 63 - 9i, so the first set type bit among those tells how long the run is
+            if (have < 9u) break;                                  // type bit, then 8 more or stop (:220-223)
+            const uint64_t types = bits & 0x8040201008040200ull;
+            uint32_t k = (types ? (uint32_t)__builtin_clzll(types) : 64u) / 9u;
+            const uint32_t fit = have / 9u;
+            k = k < fit ? k : fit;
+            k = k < room ? k : room;
+            if (lane < k) ring8[(count + lane) & kRingMask] = (uint8_t)(bits >> (55u - 9u * lane));
+            count += k;
+            bits <<= 9u * k; have -= 9u * k;
+        } else {
+            // a match token: 1 s ooooooo[oooo] cccc (:238-342).  Every field is decoded from the
+            // zero-padded buffer without asking whether its bits exist; the ONE test on `need`
+            // covers all the "not enough bits: stop" exits of the reference (:240,250,274,334),
+            // because a token produces nothing before its last field is read, and bits can only
+            // be missing when the input is exhausted (the refill above keeps more than a token's
+            // worth otherwise).
+            const uint32_t t = top >> 11;
+            const bool is_short = (t >> 19) & 1u;
+            const uint32_t o = is_short ? (t >> 12) & 0x7Fu : (t >> 8) & 0x7FFu;
+            const uint32_t used = is_short ? 9u : 13u;
+            if (o == 0u) {
+                if (have < used) break;
+                bits <<= used; have -= used;
+                if (is_short) {                                    // end marker (:255-260 / :564-576)
+                    if (!concat) break;                            // one-shot rule: stop
+                    // file rule (the incremental decoder): drop the pad bits up to the byte
+                    // boundary and go on with the next stream
+                    const uint32_t pad = have & 7u;
+                    bits <<= pad; have -= pad;
+                } else {
+                    off = 0;                                       // long offset 0: no copy (:280)
+                }
+                continue;
+            }
+            const uint32_t code = (is_short ? t >> 8 : t >> 4) & 0xFu;
+            const uint32_t len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
+            const uint32_t width = code < 0xCu ? 2u : 4u;
+            if (have < used + width) break;
+            bits <<= used + width; have -= used + width;
+            off = o;
+            extended = len == kTokenMax ? 1u : 0u;
+            copy_len = len;
+        }
+
+        if (copy_len) {                                            // :346-365, :381-400
+            const uint32_t m = copy_len < room ? copy_len : room;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t v = 0;
+            if (lane < m) {
+                // overlap replicates with period `off`; m <= 15, so only short offsets wrap
+                // (`off` is wave-uniform: the division is skipped for the common long offsets)
+                const uint32_t k = off > 15u ? lane : lane % off;
+                const uint32_t from = count + k;                   // position + off of the source
+                v = from >= off ? ring8[(from - off) & kRingMask] : 0u;   // before out[0] -> 0
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < m) ring8[(count + lane) & kRingMask] = (uint8_t)v;
+            count += m;
+        }
+
+        // ---- drain whole tiles of finished output
+        if (count - flushed >= kTile) {
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t p = flushed + 16 * lane;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&ring[(p & kRingMask) >> 2]);
+            if (dst16) {
+                *reinterpret_cast<uint4 *>(dst + p) = v;
+            } else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (uint32_t k = 0; k < 16; k++) dst[p + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            }
+            flushed += kTile;
+        }
+    }
+
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = flushed + lane; i < count; i += 64) dst[i] = ring8[i & kRingMask];
+    if (lane == 0) out_len[b] = count;
+}
+
+// ---------------------------------------------------------------------------------
 // Compaction of fixed-stride slots into one dense string.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
@@ -1849,9 +2014,15 @@ static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, u
 {
     if (nblocks == 0) return 0;
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(lzs_decompress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
-                       (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
+    static const int use_v1 = [] { const char *v = getenv("LZS_DECODER"); return v && v[0] == 'v' && v[1] == '1'; }();
+    if (use_v1)
+        hipLaunchKernelGGL(lzs_decompress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
+    else
+        hipLaunchKernelGGL(lzs_decompress_blocks_v2_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
     return (int)hipGetLastError();
 }
 
