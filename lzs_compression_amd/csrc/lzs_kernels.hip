@@ -1279,11 +1279,17 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
             }
             __syncthreads();
             PROF_MARK(0);
-            // every wave walks all batches, inserting into its own buckets
+            // Normally one pool; after an open match also the batches it ran over (at most the
+            // 2112 positions that can still be candidates, see below), half a KiB at a time: the
+            // HASH records live in the result slots, which are free then (no pool is pending).
             { PROF_T0; PROF_COUNT(17, (Se - next) >> 6);
-              wg_hash_range(L, next, Se, n, lane, wave);
-              __syncthreads();
-              wg_chain_range(L, next, Se, lane, wave);
+              for (uint32_t R = next; R < Se; R += kWgPool) {
+                  const uint32_t R2 = R + kWgPool < Se ? R + kWgPool : Se;
+                  if (R != next) __syncthreads();
+                  wg_hash_range(L, R, R2, n, lane, wave);
+                  __syncthreads();
+                  wg_chain_range(L, R, R2, lane, wave);
+              }
               PROF_T1(16); }
             next = Se;
         }
@@ -1466,32 +1472,48 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
                     }
                     o.head += off <= kShortMax ? 13u : 17u;
                     c = Pb + open_at + kTokenMax;
+                    // Up to 240 bytes = 16 nibbles per round: lane i compares the 4 bytes at
+                    // c + 4i with those `off` before.  Nothing is inserted into the chains here;
+                    // the batches run over are built with the next pool.
                     bool more = true;
-                    while (more) {                             // up to 60 bytes = 4 nibbles per round
+                    while (more) {
                         while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
                         if (o.flushed >= o.cap) break;
-                        wave_refill(L, src, n, src16, lane, loaded, c + 64);
-                        // keep the chains current while c runs ahead of the built range
-                        while (next + 128 <= c) {
-                            wg_build64(L, next, n, lane, 4);
-                            next += 64;
-                        }
+                        wave_refill(L, src, n, src16, lane, loaded, c + 260);
                         const uint32_t rem = n - c;
-                        const uint32_t span = rem < 60u ? rem : 60u;
-                        const bool differs = lane < span &&
-                                             ring_byte(L.ring, c + lane) != ring_byte(L.ring, c + lane - off);
-                        const uint64_t stopmask = __builtin_amdgcn_ballot_w64(differs) | (1ull << span);
-                        const uint32_t m = uniform((uint32_t)__builtin_ctzll(stopmask));   // equal bytes <= span
+                        const uint32_t span = rem < 240u ? rem : 240u;
+                        const uint32_t q = c + 4u * lane;
+                        const uint32_t aq = (q & kRingMask) >> 2, bq = ((q - off) & kRingMask) >> 2;
+                        const uint32_t x = __builtin_amdgcn_alignbyte(L.ring[aq + 1], L.ring[aq], q) ^
+                                           __builtin_amdgcn_alignbyte(L.ring[bq + 1], L.ring[bq], q - off);
+                        uint32_t eq = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;           // equal leading bytes
+                        const uint32_t mine = span > 4u * lane ? span - 4u * lane : 0u;    // bytes of the span in my word
+                        eq = eq < mine ? eq : mine;
+                        const uint64_t stops = __builtin_amdgcn_ballot_w64(eq < 4u);       // lanes >= 60 have mine = 0
+                        const uint32_t l = uniform((uint32_t)__builtin_ctzll(stops));
+                        const uint32_t m = 4u * l + (uint32_t)__builtin_amdgcn_readlane((int)eq, (int)l);   // equal bytes <= span
                         c += m;
                         const uint32_t full = m / kNibbleMax;
-                        more = (m == 60u);
-                        // nibbles of 15, then (unless 60 bytes matched and the run may go on)
-                        // the closing nibble 0..14
-                        const uint32_t v = more ? 0xFFFFu : ((((1u << (4 * full)) - 1u) << 4) | (m % kNibbleMax));
-                        const uint32_t wbits = more ? 16u : 4 * (full + 1);
-                        if (lane == 0) bits_or(L.bits, kWgBitWords, wg_bit_at(o), v, wbits);
-                        o.head += wbits;
+                        more = (m == 240u);
+                        // `full` nibbles of 15, then (unless all 240 bytes matched and the run may
+                        // go on) the closing nibble 0..14: up to 68 bits, 32 per lane from lane 0 on
+                        const uint32_t ones = 4u * full, seq = more ? ones : ones + 4u;
+                        if (lane < 3u) {
+                            const uint32_t a = 32u * lane;
+                            const uint32_t n1 = ones > a ? (ones - a < 32u ? ones - a : 32u) : 0u;     // ones in my piece
+                            const bool closes = !more && ones >= a && ones < a + 32u;                  // the nibble is in my piece
+                            const uint32_t width = n1 + (closes ? 4u : 0u);
+                            uint32_t v = n1 >= 32u ? ~0u : (1u << n1) - 1u;
+                            if (closes) v = (v << 4) | (m % kNibbleMax);
+                            if (width) bits_or(L.bits, kWgBitWords, (wg_bit_at(o) + a) & 8191u, v, width);
+                        }
+                        o.head += seq;
                     }
+                    // Positions the match ran over that can no longer be a candidate for anything
+                    // (more than a window before c) are never inserted: chains only ever lead from
+                    // built positions to older built ones, and every position searched from here
+                    // on looks back at most 2047.
+                    if (c > next + 2176u) next = (c - 2112u) & ~63u;
                     while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
                     if (lane == 0) {
                         L.bcast[0] = c; L.bcast[1] = loaded; L.bcast[2] = next;
