@@ -750,25 +750,30 @@ void lzs_compress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, ui
 // but ONE 256-THREAD WORKGROUP PER BLOCK.  The four waves share a single set of LDS tables
 // (ring, heads, links), which quadruples the waves a CU can hold for a given LDS budget,
 // and every phase is lane-parallel over 256 threads, separated by workgroup barriers:
-//   BUILD   each hash bucket is owned by one wave (bucket & 3), so the ordered-exchange
-//           chaining stays inside one wave instruction stream; positions inside a run of
-//           one byte value (same byte before, 13 equal bytes ahead) are not inserted at all
-//           -- they can only ever win as offset 1, which every search checks first;
-//   SEARCH  the four waves pull positions from one shared counter; a match that fills the
-//           first length code is measured on to <= 59 more bytes so that its token is
-//           complete; longer ones are left "open";
-//   PARSE   the greedy chain of token starts (lzs-compression.c:301-447) is found by pointer
-//           jumping over next[i] = i + bytes consumed at i: 10 doubling rounds mark every
-//           token start of the pool, no serial chase;
-//   PACK    marked tokens are encoded by their owning threads, a workgroup prefix sum of
-//           the bit widths places them, and complete 256-byte quarters of the bit ring go
-//           out as coalesced stores.  Only open matches (long runs) are finished by wave 0
-//           alone, 60 bytes per step.
+// Pools of 512 positions are pipelined: pool k is built and searched while pool k-1 is
+// parsed and packed (walks of pool k still running are carried into the next round).
+//   BUILD   HASH: buckets and "inserted at all" per position, dealt over the four waves;
+//           CHAIN: wave 0 / wave 1 chain the 3-byte / 2-byte buckets by ordered exchange.
+//           Positions inside a run of one byte value (same byte before, 13 equal bytes
+//           ahead) are not inserted -- they can only ever win as offset 1, the seed of
+//           every search;
+//   SEARCH  the four waves pull positions from one shared counter; one branch-free step
+//           per candidate for all 64 lanes;
+//   EXTEND  a match that fills the search cap is measured on to <= 59 more bytes so that
+//           its token is complete (only the first of each run of such positions compares
+//           bytes); longer ones are left "open";
+//   PARSE   the greedy chain of token starts (lzs-compression.c:301-447) by pointer
+//           doubling inside 64-position chunks (in registers, for every possible entry),
+//           a walk over the 8 chunk exits, and lane m taking the m-th token of its chunk;
+//   PACK    tokens are encoded by their lanes, a workgroup prefix sum of the bit widths
+//           places them, and complete 256-byte quarters of the bit ring go out as
+//           coalesced stores.  Only open matches (long runs) are finished by wave 0
+//           alone, 240 bytes per step.
+// DESIGN.md section 3.1 has the LDS table, the measurements and what bounds the kernel.
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kWgThreads  = 256;
-// 3-byte buckets: as many as the LDS left over at five workgroups per CU holds (31.0 KB per workgroup
-// still fits five, 31.5 KB does not; not a power of
-// two: the hash is scaled into the range).  A quarter fewer collisions than 1024 buckets, and a
+// 3-byte buckets: as many as the LDS left over at five workgroups per CU holds (31.0 KB per
+// workgroup still fits five, 31.5 KB does not; not a power of two: the hash is scaled into the range).  A quarter fewer collisions than 1024 buckets, and a
 // collision costs a whole SEARCH step.
 constexpr uint32_t kWgHead3    = 1256;
 constexpr uint32_t kWgPool     = 512;
@@ -884,7 +889,7 @@ __device__ __forceinline__ uint32_t *wg_dummy(BlkLds &L) { return reinterpret_ca
 // bucket is chained by one wave's in-order instruction stream; waves 2 and 3 wait (the kernel is
 // bound by VALU issue, and chaining four ways only repeated the record decoding).  No
 // exec-masked regions and no branches inside the loops: a lane that must not insert exchanges
-// with its dummy word instead.  Same chains as wg_build64().
+// with its dummy word instead.
 __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t Be, uint32_t n, uint32_t lane, uint32_t wave)
 {
     const auto text4 = [&](uint32_t q) {
@@ -916,7 +921,9 @@ __device__ __forceinline__ void wg_hash_range(BlkLds &L, uint32_t B0, uint32_t B
             const uint32_t w0 = (uint32_t)(eprev >> 32), w1 = (uint32_t)ecur, w2 = (uint32_t)(ecur >> 32), w3 = (uint32_t)enext;
             const uint32_t lo = first ? w0 : (low ? w1 : w2), hi = first ? w1 : (low ? w2 : w3);
             const uint32_t run = __builtin_amdgcn_alignbit(hi, lo, shift) & 0x1FFFu;
-            // interior of a run: the same byte before, and 13 equal bytes ahead (see wg_build64)
+            // Interior of a run: the same byte before, and 13 equal bytes ahead.  Such a position is
+            // dominated by p+1 as a candidate for every later position, and its own search ends at
+            // offset 1 (full cap), so it is neither inserted nor does it need a link.
             const uint32_t skip = opaque(run == 0x1FFFu ? 1u : 0u);
             const uint32_t h3 = wg_hash3(tcur[j]);
             const uint32_t h2 = (((tcur[j] & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
@@ -968,49 +975,6 @@ __device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t 
     uint32_t B = B0;
     for (; B + 256u <= Be; B += 256u) wg_chain_group<4>(L, B, slot, lane, heads, links, hshift, hmask, oshift);
     for (; B < Be; B += 64u) wg_chain_group<1>(L, B, slot, lane, heads, links, hshift, hmask, oshift);
-}
-
-// Insert the 64 positions starting at B.  `wave` < 4: only buckets owned by that wave
-// (called by all four waves); wave == 4: every bucket (called by one wave alone).
-__device__ __forceinline__ void wg_build64(BlkLds &L, uint32_t B, uint32_t n, uint32_t lane, uint32_t wave)
-{
-    const uint32_t p = B + lane;
-    const uint32_t a = (p & kRingMask) >> 2, sh = p & 3;
-    const uint32_t d0 = L.ring[a], d1 = L.ring[a + 1];
-    const uint32_t t0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    const uint32_t splat = (t0 & 0xFFu) * 0x01010101u;
-    // Interior of a run: the same byte before, and 13 equal bytes ahead.  Such a position is
-    // dominated by p+1 as a candidate for every later position, and its own search ends at
-    // offset 1 (full cap), so it is neither inserted nor does it need a link.
-    // Four equal bytes are the cheap necessary condition; the rest is looked at only then.
-    bool deep = false;
-    if ((__builtin_amdgcn_ballot_w64(t0 == splat) != 0ull)) {
-        const uint32_t d2 = L.ring[a + 2], d3 = L.ring[a + 3], d4 = L.ring[a + 4];
-        const uint32_t t1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        const uint32_t t2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        const uint32_t t3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        deep = t0 == splat && t1 == splat && t2 == splat && ((t3 ^ splat) & 0xFFu) == 0 && p + 13 <= n &&
-               p >= 1u && (ring_byte(L.ring, p - 1u) ^ t0) << 24 == 0;
-    }
-    const uint32_t h3 = wg_hash3(t0);
-    const uint32_t h2 = (((t0 & 0xFFFFu) * 40503u) >> 6) & (kHead2 - 1);
-    const uint32_t slot = wg_slot_base(B) + lane;
-    if (wave == 4 || (h3 & 3u) == wave) {
-        uint32_t d = kNoLink;
-        if (p + 2 < n && !deep) {
-            const uint32_t old = __hip_atomic_exchange(&L.head3[h3], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            d = p - old < kNoLink ? p - old : kNoLink;
-        }
-        L.link3[slot] = (uint16_t)d;
-    }
-    if (wave == 4 || (h2 & 3u) == wave) {
-        uint32_t d = kNoLink;
-        if (p + 1 < n && !deep) {
-            const uint32_t old = __hip_atomic_exchange(&L.head2[h2], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            d = p - old < kNoLink ? p - old : kNoLink;
-        }
-        L.link2[slot] = (uint16_t)d;
-    }
 }
 
 // EXTEND: a match that fills the search cap (12) may run on, and its token is only complete with
