@@ -241,6 +241,45 @@ def test_long_matches_across_chunk_and_pool_boundaries():
         assert c == O.compress(d)
 
 
+def test_fuzz_mixed_segments_up_to_200k_vs_oracle():
+    """Longer inputs stitched from segments of different kinds: runs and periodic repeats far
+    longer than the window (the kernel finishes those as one open match and skips most of the
+    chain inserts), text, noise and copies of earlier material at offsets around the window
+    size -- so that every kind of segment is entered from every other kind, at every phase
+    of the 512-position pools."""
+    rng = np.random.default_rng(909)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(1, 10)), dtype=np.uint8)) for _ in range(400)]
+    datas = []
+    for _ in range(60):
+        n = int(rng.integers(20_000, 200_000))
+        out = bytearray()
+        while len(out) < n:
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                out += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 7000))
+            elif kind == 1:
+                unit = bytes(rng.integers(0, 256, int(rng.integers(2, 300)), dtype=np.uint8))
+                out += unit * int(rng.integers(1, 6000 // len(unit) + 2))
+            elif kind == 2:
+                out += bytes(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8))
+            elif kind == 3:
+                for _ in range(int(rng.integers(1, 400))):
+                    out += words[int(rng.integers(0, 400))] + b" "
+            elif kind == 4 and len(out) > 100:
+                back = int(rng.integers(1, min(len(out), 2300)))
+                take = int(rng.integers(2, 400))
+                for i in range(take):                       # overlapping copy, byte by byte
+                    out.append(out[len(out) - back])
+            else:
+                out += bytes(rng.integers(0, 3, int(rng.integers(1, 2000)), dtype=np.uint8) + 120)
+        datas.append(bytes(out[:n]))
+    comps = _gpu_compress_many(datas)
+    for d, c in zip(datas, comps):
+        assert c == O.compress(d)
+    backs = _gpu_decompress_many(comps, 200_000)
+    assert backs == datas
+
+
 def test_fuzz_decoder_on_garbage_vs_oracle():
     rng = np.random.default_rng(77)
     streams = [bytes(rng.integers(0, 256, int(rng.integers(0, 400)), dtype=np.uint8)) for _ in range(300)]
