@@ -840,7 +840,10 @@ struct WgOut {
     uint8_t *dst;
     uint32_t cap;
     bool     aligned4;
+    uint32_t mode;       // kOutStore: plain stores (a block's own slot); kOutCount: no stores, bits are only
+                         // counted; kOutOr: atomic OR into zeroed memory shared with the neighbouring segments
 };
+constexpr uint32_t kOutStore = 0, kOutCount = 1, kOutOr = 2;
 
 __device__ __forceinline__ uint32_t wg_bit_at(const WgOut &o) { return ((o.flushed << 3) + o.head) & 8191u; }
 
@@ -851,6 +854,11 @@ __device__ __forceinline__ void wg_store_quarter(const WgOut &o, BlkLds &L, uint
     const uint32_t v = __builtin_bswap32(L.bits[slot]);
     L.bits[slot] = 0;
     const uint32_t at = o.flushed + 4 * lane;
+    if (o.mode == kOutCount) return;
+    if (o.mode == kOutOr) {                                   // o.dst is 4-aligned in this mode
+        if (v) atomicOr(reinterpret_cast<unsigned int *>(o.dst + at), v);
+        return;
+    }
     if (o.aligned4 && at + 4 <= o.cap) {
         *reinterpret_cast<uint32_t *>(o.dst + at) = v;
     } else {
@@ -1171,39 +1179,40 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
     W.links = links; W.resp = resp;
 }
 
-__global__ __launch_bounds__(kWgThreads)
-void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
-                                   uint32_t *__restrict__ out_len,
-                                   const uint8_t *__restrict__ in, size_t in_stride,
-                                   const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
-                                   uint32_t nblocks)
+// What one workgroup compresses: the stream `src[0..n)` from token start `c0` up to (not
+// including) the first token start >= `cend`.  A whole block: c0 = w0 = 0, cend = n.  A segment of
+// a longer stream (lzs_compress_segments_kernel): the chains are first built from `w0` (a window
+// before the segment), the bits start `o.head` bits into the 256-byte granule at `o.dst`, and the
+// end marker is only written by the last one.
+struct WgJob {
+    const uint8_t *src;
+    uint32_t n, cend, c0, w0;
+    bool last;                      // append the end marker
+    uint32_t *out_len;              // kOutStore: bytes written
+    uint32_t *exit_pos;             // other modes: first token start >= cend ...
+    unsigned long long *nbits;      // ... and the bits emitted up to there
+};
+
+__device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgOut o)
 {
-    __shared__ BlkLds L;
     const uint32_t tid  = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = uniform(tid >> 6);
-    const uint32_t b    = blockIdx.x;
-    if (b >= nblocks) return;
-
-    const uint8_t *src = in + (size_t)b * in_stride;
-    const uint32_t n   = in_len ? in_len[b] : in_len_uniform;
+    const uint8_t *src = job.src;
+    const uint32_t n   = job.n;
+    const uint32_t cend = job.cend;
+    const uint32_t head0 = o.head;
     const bool src16   = ((uintptr_t)src & 15u) == 0;
     const bool src4    = ((uintptr_t)src & 3u) == 0;
-
-    WgOut o;
-    o.flushed = 0; o.head = 0;
-    o.dst = out + (size_t)b * out_stride;
-    o.cap = out_cap;
-    o.aligned4 = ((uintptr_t)o.dst & 3u) == 0;
 
     for (uint32_t i = tid; i < kWgHead3; i += kWgThreads) L.head3[i] = ~0u;
     for (uint32_t i = tid; i < kHead2; i += kWgThreads) L.head2[i] = ~0u;
     L.bits[tid] = 0;
     __syncthreads();
 
-    uint32_t c = 0;          // start of the next token
-    uint32_t loaded = 0;     // ring holds [loaded-4096, loaded)
-    uint32_t next = 0;       // next batch of 64 positions to build
+    uint32_t c = job.c0;         // start of the next token
+    uint32_t loaded = job.w0;    // ring holds [loaded-4096, loaded)
+    uint32_t next = job.w0;      // next batch of 64 positions to build
     PROF_DECL;
 
     // The pools are pipelined: while pool k is in SEARCH, pool k-1 (searched in the round before,
@@ -1214,11 +1223,11 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     W.links = L.link2; W.resp = wg_dummy(L);
     bool pending = false;                    // a searched pool waits for PARSE
     uint32_t Pb = 0, pend = 0;               // that pool
-    const uint32_t nup = (n + 63u) & ~63u;
+    const uint32_t nup = (cend + 63u) & ~63u;                 // no pool starts past the job's end
 
     for (;;) {
         if (o.flushed >= o.cap) break;
-        if (!pending && (c >= n || next >= nup)) break;
+        if (!pending && (c >= cend || next >= nup)) break;
         PROF_MARK(4);
         // ---- the next pool [Sb, Se): REFILL (128 threads x 4 B per half KiB) and BUILD
         const bool fresh = next < nup;
@@ -1499,21 +1508,100 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     if (wave == 0) { PROF_DONE; }
     __syncthreads();                                           // the last round's bits are in
 
-    // ---- end marker 1 1 0000000, zero pad to a byte, drain (:449-466)
     if (wave == 0) {
-        if (lane == 0) bits_or(L.bits, kWgBitWords, wg_bit_at(o), 0x180u, 9);
-        o.head = (o.head + 9u + 7u) & ~7u;
+        if (o.mode != kOutStore && lane == 0) {
+            *job.exit_pos = c;
+            *job.nbits = 8ull * o.flushed + o.head - head0;    // without the end marker
+        }
+        // ---- end marker 1 1 0000000, zero pad to a byte, drain (:449-466)
+        if (job.last) {
+            if (lane == 0) bits_or(L.bits, kWgBitWords, wg_bit_at(o), 0x180u, 9);
+            o.head = (o.head + 9u + 7u) & ~7u;
+        }
         while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t nbytes = o.head >> 3;
-        for (uint32_t i = lane; i < nbytes; i += 64) {
-            const uint32_t bit = ((o.flushed << 3) + 8 * i) & 8191u;
-            const uint32_t v = (L.bits[bit >> 5] >> (24u - (bit & 24u))) & 0xFFu;
-            if (o.flushed + i < o.cap) o.dst[o.flushed + i] = (uint8_t)v;
+        if (o.mode == kOutStore) {
+            const uint32_t nbytes = o.head >> 3;
+            for (uint32_t i = lane; i < nbytes; i += 64) {
+                const uint32_t bit = ((o.flushed << 3) + 8 * i) & 8191u;
+                const uint32_t v = (L.bits[bit >> 5] >> (24u - (bit & 24u))) & 0xFFu;
+                if (o.flushed + i < o.cap) o.dst[o.flushed + i] = (uint8_t)v;
+            }
+            const uint32_t total = o.flushed + nbytes;
+            if (lane == 0) *job.out_len = total < o.cap ? total : o.cap;
+        } else if (o.mode == kOutOr) {
+            if (32u * lane < o.head) wg_store_quarter(o, L, lane);   // the words the last bits reach into
         }
-        const uint32_t total = o.flushed + nbytes;
-        if (lane == 0) out_len[b] = total < o.cap ? total : o.cap;
     }
+}
+
+__global__ __launch_bounds__(kWgThreads)
+void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
+                                   uint32_t *__restrict__ out_len,
+                                   const uint8_t *__restrict__ in, size_t in_stride,
+                                   const uint32_t *__restrict__ in_len, uint32_t in_len_uniform,
+                                   uint32_t nblocks)
+{
+    __shared__ BlkLds L;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    WgJob job;
+    job.src = in + (size_t)b * in_stride;
+    job.n = in_len ? in_len[b] : in_len_uniform;
+    job.cend = job.n; job.c0 = 0; job.w0 = 0; job.last = true;
+    job.out_len = out_len + b; job.exit_pos = nullptr; job.nbits = nullptr;
+    WgOut o;
+    o.flushed = 0; o.head = 0;
+    o.dst = out + (size_t)b * out_stride;
+    o.cap = out_cap;
+    o.aligned4 = ((uintptr_t)o.dst & 3u) == 0;
+    o.mode = kOutStore;
+    wg_compress_job(L, job, o);
+}
+
+// One long stream cut into segments of `seg` bytes (a multiple of 64), one workgroup each.  The
+// search is a pure function of (input, position), so a segment only needs the 2047 bytes before it
+// in its chains -- but where its first token starts, and at which bit its output begins, depends
+// on the segment before.  The host (lzs_host.c) runs this kernel first in counting mode with every
+// segment entered at its own start, re-runs the segments whose predecessor turned out to end its
+// last token elsewhere (`dirty`) until all entries agree, then runs it once more in OR mode with
+// the bit offsets known.  `out` is 4-aligned, zeroed, and all segments OR their bits into it.
+__global__ __launch_bounds__(kWgThreads)
+void lzs_compress_segments_kernel(uint8_t *__restrict__ out, const unsigned long long *__restrict__ bit_at,
+                                  const uint8_t *__restrict__ in, uint32_t n, uint32_t seg, uint32_t nseg,
+                                  const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
+                                  uint32_t *__restrict__ exit_pos, unsigned long long *__restrict__ nbits)
+{
+    __shared__ BlkLds L;
+    const uint32_t k = blockIdx.x;
+    if (k >= nseg) return;
+    if (dirty && !dirty[k]) return;
+    const uint32_t s = k * seg;
+    const uint32_t e = s + seg < n ? s + seg : n;              // the last segment ends with the input
+    WgJob job;
+    job.src = in; job.n = n; job.cend = e;
+    job.c0 = entry[k];
+    // chains from a window before the first token: batches of 64, and one more so that HASH sees
+    // the byte before the first position that matters
+    const uint32_t c64 = job.c0 & ~63u;
+    job.w0 = c64 > 2176u ? c64 - 2176u : 0u;
+    job.last = bit_at != nullptr && e == n;
+    job.out_len = nullptr; job.exit_pos = exit_pos + k; job.nbits = nbits + k;
+    WgOut o;
+    o.flushed = 0; o.cap = ~0u; o.aligned4 = true;
+    if (bit_at) {
+        const unsigned long long g = bit_at[k];
+        o.dst = out + 256ull * (g >> 11);
+        o.head = (uint32_t)(g & 2047ull);
+        o.mode = kOutOr;
+    } else {
+        o.dst = out; o.head = 0; o.mode = kOutCount;
+    }
+    if (job.c0 >= e && !job.last) {                            // the segment before ran over all of this one
+        if (threadIdx.x == 0) { exit_pos[k] = job.c0; nbits[k] = 0; }
+        return;
+    }
+    wg_compress_job(L, job, o);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2024,6 +2112,18 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
                                      uint32_t in_len, uint32_t nblocks, void *stream)
 {
     return launch_decompress(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, stream, 1);
+}
+
+int lzs_hip_launch_compress_segments(void *d_out, const uint64_t *d_bit_at, const void *d_in, uint32_t n,
+                                     uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
+                                     const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
+                                     void *stream)
+{
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at, (const uint8_t *)d_in, n, seg, nseg,
+                       d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits);
+    return (int)hipGetLastError();
 }
 
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,

@@ -364,6 +364,40 @@ def test_multi_megabyte_single_stream():
     assert lzs.decompress(got, len(data)) == data
 
 
+def test_one_long_stream_on_many_workgroups_vs_oracle():
+    """lzs_compress() of a buffer longer than 128 KiB is cut into 64 KiB segments, one workgroup
+    each, stitched at the bit level.  Same bytes as the reference: every class,
+    lengths that are not multiples of the segment, runs and repeats spanning many segments, and
+    a capacity that cuts the stream."""
+    rng = np.random.default_rng(31)
+    datas = []
+    for cls in workload.CLASS_NAMES:
+        blocks = workload.fill(cls, 40).reshape(-1)
+        datas.append(bytes(blocks[: 40 * 65536 - 12345]))
+        datas.append(bytes(blocks[: 131073]))
+    mix = bytearray()
+    text = bytes(workload.fill("text", 8).reshape(-1))
+    while len(mix) < 3_000_000:
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            mix += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 250_000))
+        elif k == 1:
+            a = int(rng.integers(0, len(text) - 1)); mix += text[a: a + int(rng.integers(1, 150_000))]
+        elif k == 2:
+            mix += bytes(rng.integers(0, 256, int(rng.integers(1, 70_000)), dtype=np.uint8))
+        else:
+            unit = bytes(rng.integers(0, 256, int(rng.integers(2, 2500)), dtype=np.uint8))
+            mix += unit * int(rng.integers(1, 150))
+    datas.append(bytes(mix))
+    datas.append(bytes(1_000_000))                      # one run over 15 segments
+    datas.append(text[:70_000] * 9)                     # a period longer than a segment: no matches across
+    for d in datas:
+        want = O.compress(d)
+        assert lzs.compress(d) == want
+        cut = len(want) // 3
+        assert lzs.compress(d, cut) == want[:cut]
+
+
 @pytest.mark.parametrize("variant", ["chain", "scan"])
 def test_other_kernel_variants_agree(variant):
     """The A/B variants (LZS_KERNEL=chain|scan) produce the same bytes as the default kernel."""
