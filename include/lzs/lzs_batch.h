@@ -68,6 +68,22 @@ int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, 
                                 size_t in_len, size_t nblocks, void *hip_stream);
 
 /*
+ * ONE stream from device memory, on the whole device: the result of
+ * lzs_compress(d_out, out_cap, d_in, in_len) (reference lzs-compression.c:249-467) for buffers
+ * already in HBM.  The stream is cut into 64 KiB segments, one workgroup each; where each
+ * segment's first token starts is agreed by counting rounds and the bits are placed at their
+ * global offsets, so the bytes are those of the one-shot call.
+ * The 4-argument lzs_compress() takes the same route for inputs above 128 KiB.
+ *
+ * d_out must be 4-byte aligned and hold LZS_COMPRESSED_MAX(in_len) + 1024 bytes; ALL of that is
+ * overwritten (cleared first).  The result is cut at out_cap as lzs_compress() does.  The call
+ * synchronises with the device several times (not capturable into a graph) and uses this thread's
+ * staging stream.  Returns the byte count in *out_len.
+ */
+int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
+                               const void *d_in, size_t in_len);
+
+/*
  * Gather the variable-length results of a batch into one dense byte string:
  * d_offsets[b] = sum of d_len[0..b) for b = 0..nblocks (nblocks+1 entries, uint64),
  * d_dense[d_offsets[b] .. d_offsets[b+1]) = slot b's first d_len[b] bytes.

@@ -6,10 +6,10 @@ the seeded workload generators used by the benchmark and tests.  No CPU codec, n
 fallback: without the built library or without a GPU, calls raise.
 """
 from .api import (LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
-                  compressed_max, decompress, decompress_batch, decompress_blocks, decompress_concat,
+                  compress_stream, compressed_max, decompress, decompress_batch, decompress_blocks, decompress_concat,
                   decompressed_max, last_error, lib)
 from . import workload
 
 __all__ = ["LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
-           "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_concat",
+           "compress_stream", "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_concat",
            "decompressed_max", "last_error", "lib", "workload"]

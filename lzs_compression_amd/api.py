@@ -66,6 +66,8 @@ def lib() -> ctypes.CDLL:
         for name in ("lzs_compress_batch", "lzs_decompress_batch"):
             f = getattr(L, name)
             f.restype, f.argtypes = ctypes.c_int, _BATCH_HOST
+        L.lzs_compress_stream_device.restype = ctypes.c_int
+        L.lzs_compress_stream_device.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _vp, _sz]
         L.lzs_compact_device.restype = ctypes.c_int
         L.lzs_compact_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
         _lib = L
@@ -191,6 +193,20 @@ def compress_blocks(x, in_len=None, out_capacity: Optional[int] = None, out=None
 def decompress_blocks(x, in_len, out_capacity: int, out=None, out_len=None, stream=None):
     """Device batch of independent lzs_decompress() calls; arguments as compress_blocks."""
     return _device_batch(lib().lzs_decompress_batch_device, x, in_len, out_capacity, out, out_len, stream)
+
+
+def compress_stream(x, out=None):
+    """lzs_compress_stream_device(): the device tensor ``x`` (uint8, contiguous) as ONE LZS stream,
+    compressed by the whole device (segments of 64 KiB).  Returns
+    (buffer uint8 [compressed_max(n) + 1024], nbytes); the stream is buffer[:nbytes].  Synchronous."""
+    import torch
+    n = x.numel()
+    need = compressed_max(n) + 1024
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=x.device)
+    got = _sz(0)
+    _check(lib().lzs_compress_stream_device(out.data_ptr(), out.numel(), ctypes.byref(got), x.data_ptr(), n))
+    return out, int(got.value)
 
 
 def compact(slots, lengths, stream=None):

@@ -304,9 +304,10 @@ static double now_ms(void)
 #define STREAM_SEG   65536u
 #define STREAM_MIN   (2u * STREAM_SEG)          /* shorter inputs stay with one workgroup */
 
-static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n)
+/* in/out on the host (dev == 0: staged through this thread's device buffers) or on the device */
+static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status)
 {
-    const char *who = "lzs_compress";
+    const char *who = dev ? "lzs_compress_stream_device" : "lzs_compress";
     const uint32_t nseg = (uint32_t)((n + STREAM_SEG - 1) / STREAM_SEG);
     const size_t worst = LZS_COMPRESSED_MAX(n);
     size_t result = 0;
@@ -331,8 +332,11 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     void *stream = st->stream;
     /* device arrays in one allocation: bit_at, nbits (8 B each), entry, exit (4 B each), dirty */
     const size_t aux_bytes = (size_t)nseg * (8 + 8 + 4 + 4 + 1) + 64;
-    e = staging_reserve(st, BUF_IN, n + 64, &d_in);
-    if (!e) e = staging_reserve(st, BUF_OUT, worst + 1024, &d_out);
+    if (dev) { d_in = (void *)in; d_out = out; }
+    else {
+        e = staging_reserve(st, BUF_IN, n + 64, &d_in);
+        if (!e) e = staging_reserve(st, BUF_OUT, worst + 1024, &d_out);
+    }
     if (!e) e = staging_reserve(st, BUF_AUX, aux_bytes, &d_aux);
     if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
     uint64_t *d_bitat = (uint64_t *)d_aux;
@@ -343,7 +347,7 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
 
     const int debug = getenv("LZS_STREAM_DEBUG") != NULL;      /* stage times on stderr */
     double t0 = debug ? now_ms() : 0, t1;
-    HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
+    if (!dev) HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
     HIP_TRY(lzs_hip_memset(d_out, 0, worst + 1024, stream), "hipMemset");
     if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: %zu B, %u segments; H2D + memset %.2f ms\n", n, nseg, t1 - t0); t0 = t1; }
     for (uint32_t k = 0; k < nseg; k++) { entry[k] = k * STREAM_SEG; dirty[k] = 1; }
@@ -374,7 +378,7 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: pack %.2f ms\n", t1 - t0); t0 = t1; }
     result = (size_t)((total + 9 + 7) / 8);                    /* end marker, padded to a byte */
     if (result > cap) result = cap;                            /* cut at the capacity, prefix unchanged */
-    HIP_TRY(lzs_hip_d2h(out, d_out, result, stream), "hipMemcpy D2H");
+    if (!dev) HIP_TRY(lzs_hip_d2h(out, d_out, result, stream), "hipMemcpy D2H");
     HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
 #undef HIP_TRY
     goto done;
@@ -382,18 +386,31 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
 failed:
     result = 0;
     if (rc == LZS_OK) rc = LZS_E_HIP;
-    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+    if (!dev) fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
 done:
     free(entry); free(exitp); free(nbits); free(bitat); free(dirty);
     { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
+    if (status) *status = rc;
     return result;
+}
+
+int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len, const void *d_in, size_t in_len)
+{
+    if (!out_len) return fail(LZS_E_ARG, "lzs_compress_stream_device: out_len is NULL");
+    *out_len = 0;
+    if (!d_out || (!d_in && in_len)) return fail(LZS_E_ARG, "lzs_compress_stream_device: NULL buffer");
+    if (((uintptr_t)d_out & 3u) != 0) return fail(LZS_E_ARG, "lzs_compress_stream_device: d_out is not 4-byte aligned");
+    if (in_len == 0 || in_len > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "lzs_compress_stream_device: length must be 1..LZS_BLOCK_MAX");
+    int rc = LZS_OK;
+    *out_len = stream_compress((uint8_t *)d_out, out_cap, (const uint8_t *)d_in, in_len, 1, &rc);
+    return rc;
 }
 
 size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
     if (a_inLen > STREAM_MIN && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && !getenv("LZS_ONE_WORKGROUP"))
-        return stream_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+        return stream_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
     return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
 

@@ -398,6 +398,24 @@ def test_one_long_stream_on_many_workgroups_vs_oracle():
         assert lzs.compress(d, cut) == want[:cut]
 
 
+def test_stream_device_entry_point_1gib_text():
+    """lzs_compress_stream_device() at full size: 1 GiB of text as ONE stream (16384 segments).
+    The oracle needs minutes for that, so the first 24 MiB of input are compressed by the oracle
+    and compared byte for byte: the stream of a prefix is a prefix of the stream, up to the last
+    tokens before the cut (a token looks at most 12 + 59 bytes ahead) and the end marker."""
+    import torch
+    x = torch.from_numpy(workload.fill("text", 16384)).cuda()
+    out, nbytes = lzs.compress_stream(x.reshape(-1))
+    head = bytes(x.reshape(-1)[: 24 << 20].cpu().numpy())
+    want = O.compress(head)
+    got = bytes(out[: len(want)].cpu().numpy())
+    # the stream of a prefix is a prefix of the stream, up to the last few tokens before the cut
+    # (the search looks at most 12 + 59 bytes ahead of a token start; the oracle's end marker differs)
+    keep = len(want) - 64
+    assert got[:keep] == want[:keep]
+    assert 0.5 < nbytes / x.numel() < 0.6
+
+
 @pytest.mark.parametrize("variant", ["chain", "scan"])
 def test_other_kernel_variants_agree(variant):
     """The A/B variants (LZS_KERNEL=chain|scan) produce the same bytes as the default kernel."""
