@@ -39,11 +39,12 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
                                      const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                                      uint32_t in_len, uint32_t nblocks, void *stream);
 /* One long stream in segments of `seg` bytes (lzs_compress_segments_kernel): counting mode when
- * d_bit_at is NULL (only segments with d_dirty[k] != 0 run), else OR mode into zeroed d_out. */
+ * d_bit_at is NULL (only segments with d_dirty[k] != 0 run), else OR mode into zeroed d_out.
+ * d_keep (n words, may be NULL): search results, written when counting, replayed when packing. */
 int lzs_hip_launch_compress_segments(void *d_out, const uint64_t *d_bit_at, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
-                                     void *stream);
+                                     uint32_t *d_keep, void *stream);
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks,
                            void *stream);

@@ -116,7 +116,7 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
 /* Each host thread keeps one HIP stream and four grow-only device buffers for the host-buffer
  * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
  * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
-enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_COUNT };
+enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_COUNT };
 #define KEEP_MAX ((size_t)256 << 20)
 
 typedef struct {
@@ -165,10 +165,23 @@ static int staging_reserve(staging_t *st, int which, size_t bytes, void **out)
     return 0;
 }
 
+/* Buffers above the limit are released right after the call (LZS_KEEP_MAX_MB overrides the
+ * default of 256 MiB per buffer for programs that compress large buffers over and over). */
+static size_t keep_max(void)
+{
+    static size_t limit = 0;
+    if (!limit) {
+        const char *v = getenv("LZS_KEEP_MAX_MB");
+        const unsigned long mb = v ? strtoul(v, NULL, 10) : 0;
+        limit = mb ? (size_t)mb << 20 : KEEP_MAX;
+    }
+    return limit;
+}
+
 static void staging_trim(staging_t *st)
 {
     for (int i = 0; i < BUF_COUNT; i++)
-        if (st->cap[i] > KEEP_MAX) { lzs_hip_free(st->buf[i]); st->buf[i] = NULL; st->cap[i] = 0; }
+        if (st->cap[i] > keep_max()) { lzs_hip_free(st->buf[i]); st->buf[i] = NULL; st->cap[i] = 0; }
 }
 
 /* -------------------------------------------------------------------- host batches */
@@ -338,6 +351,10 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
         if (!e) e = staging_reserve(st, BUF_OUT, worst + 1024, &d_out);
     }
     if (!e) e = staging_reserve(st, BUF_AUX, aux_bytes, &d_aux);
+    /* the search results of the counting pass, one word per position, for the packing pass; if
+     * the device cannot spare 4n bytes the packing pass searches again */
+    void *d_keep = NULL;
+    if (!e && staging_reserve(st, BUF_KEEP, 4 * n + 64, &d_keep)) d_keep = NULL;
     if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
     uint64_t *d_bitat = (uint64_t *)d_aux;
     uint64_t *d_nbits = d_bitat + nseg;
@@ -355,7 +372,7 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_compress_segments(d_out, NULL, d_in, (uint32_t)n, STREAM_SEG, nseg, d_entry,
-                                                 d_dirty, d_exit, d_nbits, stream), who);
+                                                 d_dirty, d_exit, d_nbits, (uint32_t *)d_keep, stream), who);
         HIP_TRY(lzs_hip_d2h(exitp, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         /* a segment is entered where the one before stopped (its own start for segment 0) */
@@ -374,7 +391,7 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     for (uint32_t k = 0; k < nseg; k++) { bitat[k] = total; total += nbits[k]; }
     HIP_TRY(lzs_hip_h2d(d_bitat, bitat, sizeof(uint64_t) * nseg, stream), "hipMemcpy H2D");
     HIP_TRY(lzs_hip_launch_compress_segments(d_out, d_bitat, d_in, (uint32_t)n, STREAM_SEG, nseg, d_entry,
-                                             NULL, d_exit, d_nbits, stream), who);
+                                             NULL, d_exit, d_nbits, (uint32_t *)d_keep, stream), who);
     if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: pack %.2f ms\n", t1 - t0); t0 = t1; }
     result = (size_t)((total + 9 + 7) / 8);                    /* end marker, padded to a byte */
     if (result > cap) result = cap;                            /* cut at the capacity, prefix unchanged */

@@ -992,8 +992,11 @@ __device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t 
 // position, so only the first of each such run (per 64-position chunk) compares bytes -- up to
 // kTokenMax + kExtMax + 1 of them -- and the others derive theirs.  Beyond that the match is
 // "open" (finished serially in PARSE), and so is everything derived from an open one.
+// `keep` (segments of one long stream only): the search results of the whole stream in HBM, one
+// word per position -- written here in the counting pass, read back instead of searching again
+// in the packing pass (`replay`).
 __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry, uint32_t npos, uint32_t n, uint32_t lane, uint32_t wave,
-                                          uint32_t (&rr)[2])
+                                          uint32_t (&rr)[2], uint32_t *keep, bool replay)
 {
     constexpr uint32_t kRoom = kTokenMax + kExtMax + 1;
 #pragma unroll
@@ -1003,7 +1006,9 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         if (64u * wave + 256u * h >= npos) continue;           // chunk past the end of the pool (uniform)
         const uint32_t p = Pb + gi;
         // SEARCH stored (len << 16) - offset; offset 0 = no match
-        const uint32_t k = L.res[p & (kWgResN - 1)];
+        uint32_t k;
+        if (replay) { k = keep[p]; L.res[p & (kWgResN - 1)] = k; }      // (the open-match path reads the slot)
+        else        { k = L.res[p & (kWgResN - 1)]; if (keep && gi < npos) keep[p] = k; }
         const uint32_t off = (0u - k) & 0xFFFFu;
         const uint32_t len = off ? (k + 0xFFFFu) >> 16 : 0u;
         const uint32_t r = off | (len << 11);
@@ -1188,6 +1193,8 @@ struct WgJob {
     const uint8_t *src;
     uint32_t n, cend, c0, w0;
     bool last;                      // append the end marker
+    uint32_t *keep;                 // segments: search results of the whole stream in HBM (or null)
+    bool replay;                    // take them from there instead of searching
     uint32_t *out_len;              // kOutStore: bytes written
     uint32_t *exit_pos;             // other modes: first token start >= cend ...
     unsigned long long *nbits;      // ... and the bits emitted up to there
@@ -1256,7 +1263,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
             // 2112 positions that can still be candidates, see below), half a KiB at a time: the
             // HASH records live in the result slots, which are free then (no pool is pending).
             { PROF_T0; PROF_COUNT(17, (Se - next) >> 6);
-              for (uint32_t R = next; R < Se; R += kWgPool) {
+              for (uint32_t R = next; R < Se && !job.replay; R += kWgPool) {
                   const uint32_t R2 = R + kWgPool < Se ? R + kWgPool : Se;
                   if (R != next) __syncthreads();
                   wg_hash_range(L, R, R2, n, lane, wave);
@@ -1272,7 +1279,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
         PROF_MARK(1);
 
         // ---- SEARCH the new pool; ends every walk for the pending one
-        wg_search(L, W, Sb, send, n, lane SEARCH_PROF_ARGS);
+        if (!job.replay) wg_search(L, W, Sb, send, n, lane SEARCH_PROF_ARGS);
         PROF_MARK(2);
         __syncthreads();
         PROF_MARK(5);
@@ -1293,7 +1300,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
         const uint32_t npos = pend - Pb;
         PROF_STAMP0;
         uint32_t rr[2];                                        // results of this thread's two positions, complete
-        wg_extend(L, Pb, c - Pb, npos, n, lane, wave, rr);
+        wg_extend(L, Pb, c - Pb, npos, n, lane, wave, rr, job.keep, job.replay);
         PROF_STAMP(20);
         while (c < pend && o.flushed < o.cap) {
             const uint32_t entry = c - Pb;
@@ -1548,7 +1555,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     WgJob job;
     job.src = in + (size_t)b * in_stride;
     job.n = in_len ? in_len[b] : in_len_uniform;
-    job.cend = job.n; job.c0 = 0; job.w0 = 0; job.last = true;
+    job.cend = job.n; job.c0 = 0; job.w0 = 0; job.last = true; job.keep = nullptr; job.replay = false;
     job.out_len = out_len + b; job.exit_pos = nullptr; job.nbits = nullptr;
     WgOut o;
     o.flushed = 0; o.head = 0;
@@ -1570,7 +1577,8 @@ __global__ __launch_bounds__(kWgThreads)
 void lzs_compress_segments_kernel(uint8_t *__restrict__ out, const unsigned long long *__restrict__ bit_at,
                                   const uint8_t *__restrict__ in, uint32_t n, uint32_t seg, uint32_t nseg,
                                   const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
-                                  uint32_t *__restrict__ exit_pos, unsigned long long *__restrict__ nbits)
+                                  uint32_t *__restrict__ exit_pos, unsigned long long *__restrict__ nbits,
+                                  uint32_t *keep)
 {
     __shared__ BlkLds L;
     const uint32_t k = blockIdx.x;
@@ -1586,6 +1594,7 @@ void lzs_compress_segments_kernel(uint8_t *__restrict__ out, const unsigned long
     const uint32_t c64 = job.c0 & ~63u;
     job.w0 = c64 > 2176u ? c64 - 2176u : 0u;
     job.last = bit_at != nullptr && e == n;
+    job.keep = keep; job.replay = keep != nullptr && bit_at != nullptr;
     job.out_len = nullptr; job.exit_pos = exit_pos + k; job.nbits = nbits + k;
     WgOut o;
     o.flushed = 0; o.cap = ~0u; o.aligned4 = true;
@@ -2117,12 +2126,12 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
 int lzs_hip_launch_compress_segments(void *d_out, const uint64_t *d_bit_at, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
-                                     void *stream)
+                                     uint32_t *d_keep, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
                        (uint8_t *)d_out, (const unsigned long long *)d_bit_at, (const uint8_t *)d_in, n, seg, nseg,
-                       d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits);
+                       d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits, d_keep);
     return (int)hipGetLastError();
 }
 
