@@ -71,8 +71,8 @@ int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, 
  * ONE stream from device memory, on the whole device: the result of
  * lzs_compress(d_out, out_cap, d_in, in_len) (reference lzs-compression.c:249-467) for buffers
  * already in HBM.  The stream is cut into 64 KiB segments, one workgroup each; where each
- * segment's first token starts is agreed by counting rounds and the bits are placed at their
- * global offsets, so the bytes are those of the one-shot call.
+ * segment's first token starts is agreed in a few rounds and the segments' bits are shifted to
+ * their global offsets, so the bytes are those of the one-shot call.
  * The 4-argument lzs_compress() takes the same route for inputs above 128 KiB.
  *
  * d_out must be 4-byte aligned and hold LZS_COMPRESSED_MAX(in_len) + 1024 bytes; ALL of that is

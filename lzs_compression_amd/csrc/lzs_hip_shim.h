@@ -38,13 +38,19 @@ int lzs_hip_launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, 
 int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                                      const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                                      uint32_t in_len, uint32_t nblocks, void *stream);
-/* One long stream in segments of `seg` bytes (lzs_compress_segments_kernel): counting mode when
- * d_bit_at is NULL (only segments with d_dirty[k] != 0 run), else OR mode into zeroed d_out.
- * d_keep (n words, may be NULL): search results, written when counting, replayed when packing. */
-int lzs_hip_launch_compress_segments(void *d_out, const uint64_t *d_bit_at, const void *d_in, uint32_t n,
+/* One long stream in segments of `seg` bytes (lzs_compress_segments_kernel): segment k, entered
+ * at d_entry[k], writes its bits to slot k and reports where its last token ends and its bit
+ * count; only segments with d_dirty[k] != 0 run (NULL: all).  lzs_stitch_segments_kernel then ORs
+ * the slots into the zeroed, 4-aligned d_out at d_bit_at[k] and appends the end marker.  A segment
+ * whose bits did not fit its slot (d_nbits[k] > 8 * slot_stride: a very long match) is run once more
+ * with d_out / d_bit_at set and ORs its bits in directly. */
+int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
-                                     uint32_t *d_keep, void *stream);
+                                     void *d_out, const uint64_t *d_bit_at, void *stream);
+int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot_stride,
+                                   const uint64_t *d_bit_at, const uint64_t *d_nbits, uint32_t nseg,
+                                   void *stream);
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks,
                            void *stream);

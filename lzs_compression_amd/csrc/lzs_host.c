@@ -298,15 +298,16 @@ static size_t one_shot(const char *who, launch_fn launch, uint8_t *out, size_t c
 /* ------------------------------------------------ one long stream on the whole device */
 /* lzs_compress() of a buffer too long for one workgroup to be worth waiting for.  The search is a
  * pure function of (input, position), so the stream is cut into 64 KiB segments, one workgroup
- * each (lzs_compress_segments_kernel).  What a segment cannot know by itself is where its first
- * token starts -- the last token of the segment before usually reaches a few bytes into it --
- * and at which bit its output begins.  So: (1) every segment counts its bits entered at its own
- * start and reports where its last token ends; (2) segments whose predecessor ended elsewhere are
- * counted again from there, until all entries agree (the greedy parses from two nearby entries
- * merge after a few tokens, so a second round changes almost no exit; a long run simply skips
- * the segments it covers); (3) prefix sum of the bit counts on the host; (4) every segment packs
- * its tokens and ORs them into the zeroed output at its bit offset.  Same bytes as one workgroup
- * (or the reference) produces, about 2.5x the work of independent blocks. */
+ * each (lzs_compress_segments_kernel), every one writing its bits into a slot of its own.  What a
+ * segment cannot know by itself is where its first token starts -- the last token of the segment
+ * before usually reaches a few bytes into it -- and at which bit its output begins.  So: (1)
+ * every segment is compressed entered at its own start and reports where its last token ends;
+ * (2) segments whose predecessor ended elsewhere are compressed again from there, until all
+ * entries agree (the greedy parses from two nearby entries merge after a few tokens, so a second
+ * round changes almost no exit; a long run simply skips the segments it covers); (3) prefix sum
+ * of the bit counts on the host; (4) lzs_stitch_segments_kernel shifts every slot to its bit
+ * offset in the zeroed output and appends the end marker.  Same bytes as one workgroup (or the
+ * reference) produces. */
 static double now_ms(void)
 {
     struct timespec ts;
@@ -325,7 +326,8 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     const size_t worst = LZS_COMPRESSED_MAX(n);
     size_t result = 0;
     int e = 0, rc = LZS_OK;
-    void *d_in = NULL, *d_out = NULL, *d_aux = NULL;
+    void *d_in = NULL, *d_out = NULL, *d_aux = NULL, *d_slots = NULL;
+    const size_t slot_stride = (LZS_COMPRESSED_MAX((size_t)STREAM_SEG) + 15u) & ~(size_t)15u;
     uint32_t *entry = NULL, *exitp = NULL;
     uint64_t *nbits = NULL, *bitat = NULL;
     uint8_t *dirty = NULL;
@@ -351,10 +353,7 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
         if (!e) e = staging_reserve(st, BUF_OUT, worst + 1024, &d_out);
     }
     if (!e) e = staging_reserve(st, BUF_AUX, aux_bytes, &d_aux);
-    /* the search results of the counting pass, one word per position, for the packing pass; if
-     * the device cannot spare 4n bytes the packing pass searches again */
-    void *d_keep = NULL;
-    if (!e && staging_reserve(st, BUF_KEEP, 4 * n + 64, &d_keep)) d_keep = NULL;
+    if (!e) e = staging_reserve(st, BUF_KEEP, slot_stride * nseg + 64, &d_slots);
     if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
     uint64_t *d_bitat = (uint64_t *)d_aux;
     uint64_t *d_nbits = d_bitat + nseg;
@@ -371,8 +370,8 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     for (uint32_t round = 0, ndirty = nseg; ndirty; round++) {
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
-        HIP_TRY(lzs_hip_launch_compress_segments(d_out, NULL, d_in, (uint32_t)n, STREAM_SEG, nseg, d_entry,
-                                                 d_dirty, d_exit, d_nbits, (uint32_t *)d_keep, stream), who);
+        HIP_TRY(lzs_hip_launch_compress_segments(d_slots, slot_stride, d_in, (uint32_t)n, STREAM_SEG, nseg,
+                                                 d_entry, d_dirty, d_exit, d_nbits, NULL, NULL, stream), who);
         HIP_TRY(lzs_hip_d2h(exitp, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         /* a segment is entered where the one before stopped (its own start for segment 0) */
@@ -383,16 +382,24 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
             dirty[k] = exitp[k - 1] != entry[k];
             if (dirty[k]) { entry[k] = exitp[k - 1]; ndirty++; }
         }
-        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream: round %u counted %u segments in %.2f ms; %u to redo\n", round, was, t1 - t0, ndirty); t0 = t1; }
+        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream: round %u compressed %u segments in %.2f ms; %u to redo\n", round, was, t1 - t0, ndirty); t0 = t1; }
     }
     HIP_TRY(lzs_hip_d2h(nbits, d_nbits, sizeof(uint64_t) * nseg, stream), "hipMemcpy D2H");
     HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
     uint64_t total = 0;
     for (uint32_t k = 0; k < nseg; k++) { bitat[k] = total; total += nbits[k]; }
     HIP_TRY(lzs_hip_h2d(d_bitat, bitat, sizeof(uint64_t) * nseg, stream), "hipMemcpy H2D");
-    HIP_TRY(lzs_hip_launch_compress_segments(d_out, d_bitat, d_in, (uint32_t)n, STREAM_SEG, nseg, d_entry,
-                                             NULL, d_exit, d_nbits, (uint32_t *)d_keep, stream), who);
-    if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: pack %.2f ms\n", t1 - t0); t0 = t1; }
+    HIP_TRY(lzs_hip_launch_stitch_segments(d_out, d_slots, slot_stride, d_bitat, d_nbits, nseg, stream), who);
+    /* segments whose bits did not fit their slot (a match running on for more than ~120 KB past
+     * the segment): once more, ORed straight into place */
+    uint32_t nbig = 0;
+    for (uint32_t k = 0; k < nseg; k++) { dirty[k] = nbits[k] > 8u * (uint64_t)slot_stride; nbig += dirty[k]; }
+    if (nbig) {
+        HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_launch_compress_segments(d_slots, slot_stride, d_in, (uint32_t)n, STREAM_SEG, nseg,
+                                                 d_entry, d_dirty, d_exit, d_nbits, d_out, d_bitat, stream), who);
+    }
+    if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: stitch %.2f ms\n", t1 - t0); t0 = t1; }
     result = (size_t)((total + 9 + 7) / 8);                    /* end marker, padded to a byte */
     if (result > cap) result = cap;                            /* cut at the capacity, prefix unchanged */
     if (!dev) HIP_TRY(lzs_hip_d2h(out, d_out, result, stream), "hipMemcpy D2H");

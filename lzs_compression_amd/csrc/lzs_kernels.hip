@@ -840,10 +840,12 @@ struct WgOut {
     uint8_t *dst;
     uint32_t cap;
     bool     aligned4;
-    uint32_t mode;       // kOutStore: plain stores (a block's own slot); kOutCount: no stores, bits are only
-                         // counted; kOutOr: atomic OR into zeroed memory shared with the neighbouring segments
+    // Segments of one long stream only: `cap` above stays unlimited (the bits are counted to the
+    // end whatever happens), stores stop at `limit` (the slot), or -- `ored` -- go to zeroed memory
+    // shared with the neighbouring segments by atomic OR.  A block: limit = cap.
+    uint32_t limit;
+    bool     ored;
 };
-constexpr uint32_t kOutStore = 0, kOutCount = 1, kOutOr = 2;
 
 __device__ __forceinline__ uint32_t wg_bit_at(const WgOut &o) { return ((o.flushed << 3) + o.head) & 8191u; }
 
@@ -854,16 +856,15 @@ __device__ __forceinline__ void wg_store_quarter(const WgOut &o, BlkLds &L, uint
     const uint32_t v = __builtin_bswap32(L.bits[slot]);
     L.bits[slot] = 0;
     const uint32_t at = o.flushed + 4 * lane;
-    if (o.mode == kOutCount) return;
-    if (o.mode == kOutOr) {                                   // o.dst is 4-aligned in this mode
+    if (o.ored) {                                             // o.dst is 4-aligned in this mode
         if (v) atomicOr(reinterpret_cast<unsigned int *>(o.dst + at), v);
         return;
     }
-    if (o.aligned4 && at + 4 <= o.cap) {
+    if (o.aligned4 && at + 4 <= o.limit) {
         *reinterpret_cast<uint32_t *>(o.dst + at) = v;
     } else {
         for (uint32_t k = 0; k < 4; k++)
-            if (at + k < o.cap) o.dst[at + k] = (uint8_t)(v >> (8 * k));
+            if (at + k < o.limit) o.dst[at + k] = (uint8_t)(v >> (8 * k));
     }
 }
 
@@ -992,11 +993,8 @@ __device__ __forceinline__ void wg_chain_range(BlkLds &L, uint32_t B0, uint32_t 
 // position, so only the first of each such run (per 64-position chunk) compares bytes -- up to
 // kTokenMax + kExtMax + 1 of them -- and the others derive theirs.  Beyond that the match is
 // "open" (finished serially in PARSE), and so is everything derived from an open one.
-// `keep` (segments of one long stream only): the search results of the whole stream in HBM, one
-// word per position -- written here in the counting pass, read back instead of searching again
-// in the packing pass (`replay`).
 __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry, uint32_t npos, uint32_t n, uint32_t lane, uint32_t wave,
-                                          uint32_t (&rr)[2], uint32_t *keep, bool replay)
+                                          uint32_t (&rr)[2])
 {
     constexpr uint32_t kRoom = kTokenMax + kExtMax + 1;
 #pragma unroll
@@ -1006,9 +1004,7 @@ __device__ __forceinline__ void wg_extend(BlkLds &L, uint32_t Pb, uint32_t entry
         if (64u * wave + 256u * h >= npos) continue;           // chunk past the end of the pool (uniform)
         const uint32_t p = Pb + gi;
         // SEARCH stored (len << 16) - offset; offset 0 = no match
-        uint32_t k;
-        if (replay) { k = keep[p]; L.res[p & (kWgResN - 1)] = k; }      // (the open-match path reads the slot)
-        else        { k = L.res[p & (kWgResN - 1)]; if (keep && gi < npos) keep[p] = k; }
+        const uint32_t k = L.res[p & (kWgResN - 1)];
         const uint32_t off = (0u - k) & 0xFFFFu;
         const uint32_t len = off ? (k + 0xFFFFu) >> 16 : 0u;
         const uint32_t r = off | (len << 11);
@@ -1187,17 +1183,15 @@ __device__ __forceinline__ void wg_search(BlkLds &L, Walk &W, uint32_t Pb, uint3
 // What one workgroup compresses: the stream `src[0..n)` from token start `c0` up to (not
 // including) the first token start >= `cend`.  A whole block: c0 = w0 = 0, cend = n.  A segment of
 // a longer stream (lzs_compress_segments_kernel): the chains are first built from `w0` (a window
-// before the segment), the bits start `o.head` bits into the 256-byte granule at `o.dst`, and the
-// end marker is only written by the last one.
+// before the segment), there is no end marker, and where the last token ends and how many bits
+// were written is reported for the stitching.
 struct WgJob {
     const uint8_t *src;
     uint32_t n, cend, c0, w0;
     bool last;                      // append the end marker
-    uint32_t *keep;                 // segments: search results of the whole stream in HBM (or null)
-    bool replay;                    // take them from there instead of searching
-    uint32_t *out_len;              // kOutStore: bytes written
-    uint32_t *exit_pos;             // other modes: first token start >= cend ...
-    unsigned long long *nbits;      // ... and the bits emitted up to there
+    uint32_t *out_len;              // bytes written (a block), or null
+    uint32_t *exit_pos;             // a segment: first token start >= cend ...
+    unsigned long long *nbits;      // ... and the bits emitted up to there; or null
 };
 
 __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgOut o)
@@ -1263,7 +1257,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
             // 2112 positions that can still be candidates, see below), half a KiB at a time: the
             // HASH records live in the result slots, which are free then (no pool is pending).
             { PROF_T0; PROF_COUNT(17, (Se - next) >> 6);
-              for (uint32_t R = next; R < Se && !job.replay; R += kWgPool) {
+              for (uint32_t R = next; R < Se; R += kWgPool) {
                   const uint32_t R2 = R + kWgPool < Se ? R + kWgPool : Se;
                   if (R != next) __syncthreads();
                   wg_hash_range(L, R, R2, n, lane, wave);
@@ -1279,7 +1273,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
         PROF_MARK(1);
 
         // ---- SEARCH the new pool; ends every walk for the pending one
-        if (!job.replay) wg_search(L, W, Sb, send, n, lane SEARCH_PROF_ARGS);
+        wg_search(L, W, Sb, send, n, lane SEARCH_PROF_ARGS);
         PROF_MARK(2);
         __syncthreads();
         PROF_MARK(5);
@@ -1300,7 +1294,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
         const uint32_t npos = pend - Pb;
         PROF_STAMP0;
         uint32_t rr[2];                                        // results of this thread's two positions, complete
-        wg_extend(L, Pb, c - Pb, npos, n, lane, wave, rr, job.keep, job.replay);
+        wg_extend(L, Pb, c - Pb, npos, n, lane, wave, rr);
         PROF_STAMP(20);
         while (c < pend && o.flushed < o.cap) {
             const uint32_t entry = c - Pb;
@@ -1516,9 +1510,9 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
     __syncthreads();                                           // the last round's bits are in
 
     if (wave == 0) {
-        if (o.mode != kOutStore && lane == 0) {
+        if (job.exit_pos && lane == 0) {
             *job.exit_pos = c;
-            *job.nbits = 8ull * o.flushed + o.head - head0;    // without the end marker
+            *job.nbits = 8ull * o.flushed + o.head - head0;        // without an end marker
         }
         // ---- end marker 1 1 0000000, zero pad to a byte, drain (:449-466)
         if (job.last) {
@@ -1527,18 +1521,18 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
         }
         while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
         __builtin_amdgcn_wave_barrier();
-        if (o.mode == kOutStore) {
-            const uint32_t nbytes = o.head >> 3;
+        const uint32_t nbytes = (o.head + 7u) >> 3;                // a segment may end inside a byte
+        if (o.ored) {
+            if (32u * lane < o.head) wg_store_quarter(o, L, lane);     // the words the last bits reach into
+        } else {
             for (uint32_t i = lane; i < nbytes; i += 64) {
                 const uint32_t bit = ((o.flushed << 3) + 8 * i) & 8191u;
                 const uint32_t v = (L.bits[bit >> 5] >> (24u - (bit & 24u))) & 0xFFu;
-                if (o.flushed + i < o.cap) o.dst[o.flushed + i] = (uint8_t)v;
+                if (o.flushed + i < o.limit) o.dst[o.flushed + i] = (uint8_t)v;
             }
-            const uint32_t total = o.flushed + nbytes;
-            if (lane == 0) *job.out_len = total < o.cap ? total : o.cap;
-        } else if (o.mode == kOutOr) {
-            if (32u * lane < o.head) wg_store_quarter(o, L, lane);   // the words the last bits reach into
         }
+        const uint32_t total = o.flushed + nbytes;
+        if (job.out_len && lane == 0) *job.out_len = total < o.cap ? total : o.cap;
     }
 }
 
@@ -1555,30 +1549,31 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     WgJob job;
     job.src = in + (size_t)b * in_stride;
     job.n = in_len ? in_len[b] : in_len_uniform;
-    job.cend = job.n; job.c0 = 0; job.w0 = 0; job.last = true; job.keep = nullptr; job.replay = false;
+    job.cend = job.n; job.c0 = 0; job.w0 = 0; job.last = true;
     job.out_len = out_len + b; job.exit_pos = nullptr; job.nbits = nullptr;
     WgOut o;
     o.flushed = 0; o.head = 0;
     o.dst = out + (size_t)b * out_stride;
     o.cap = out_cap;
     o.aligned4 = ((uintptr_t)o.dst & 3u) == 0;
-    o.mode = kOutStore;
+    o.limit = out_cap; o.ored = false;
     wg_compress_job(L, job, o);
 }
 
 // One long stream cut into segments of `seg` bytes (a multiple of 64), one workgroup each.  The
 // search is a pure function of (input, position), so a segment only needs the 2047 bytes before it
 // in its chains -- but where its first token starts, and at which bit its output begins, depends
-// on the segment before.  The host (lzs_host.c) runs this kernel first in counting mode with every
-// segment entered at its own start, re-runs the segments whose predecessor turned out to end its
-// last token elsewhere (`dirty`) until all entries agree, then runs it once more in OR mode with
-// the bit offsets known.  `out` is 4-aligned, zeroed, and all segments OR their bits into it.
+// on the segment before.  Every segment writes its bits into a slot of its own, as if it began at
+// bit 0; the host (lzs_host.c) enters every segment at its own start first, re-runs the segments
+// whose predecessor turned out to end its last token elsewhere (`dirty`) until all entries agree,
+// takes the prefix sum of the bit counts and has lzs_stitch_segments_kernel shift the slots into
+// place.
 __global__ __launch_bounds__(kWgThreads)
-void lzs_compress_segments_kernel(uint8_t *__restrict__ out, const unsigned long long *__restrict__ bit_at,
+void lzs_compress_segments_kernel(uint8_t *__restrict__ slots, size_t slot_stride,
                                   const uint8_t *__restrict__ in, uint32_t n, uint32_t seg, uint32_t nseg,
                                   const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
                                   uint32_t *__restrict__ exit_pos, unsigned long long *__restrict__ nbits,
-                                  uint32_t *keep)
+                                  uint8_t *__restrict__ out, const unsigned long long *__restrict__ bit_at)
 {
     __shared__ BlkLds L;
     const uint32_t k = blockIdx.x;
@@ -1593,24 +1588,61 @@ void lzs_compress_segments_kernel(uint8_t *__restrict__ out, const unsigned long
     // the byte before the first position that matters
     const uint32_t c64 = job.c0 & ~63u;
     job.w0 = c64 > 2176u ? c64 - 2176u : 0u;
-    job.last = bit_at != nullptr && e == n;
-    job.keep = keep; job.replay = keep != nullptr && bit_at != nullptr;
+    job.last = false;
     job.out_len = nullptr; job.exit_pos = exit_pos + k; job.nbits = nbits + k;
-    WgOut o;
-    o.flushed = 0; o.cap = ~0u; o.aligned4 = true;
-    if (bit_at) {
-        const unsigned long long g = bit_at[k];
-        o.dst = out + 256ull * (g >> 11);
-        o.head = (uint32_t)(g & 2047ull);
-        o.mode = kOutOr;
-    } else {
-        o.dst = out; o.head = 0; o.mode = kOutCount;
-    }
-    if (job.c0 >= e && !job.last) {                            // the segment before ran over all of this one
+    if (job.c0 >= e) {                                         // the segment before ran over all of this one
         if (threadIdx.x == 0) { exit_pos[k] = job.c0; nbits[k] = 0; }
         return;
     }
+    WgOut o;
+    o.flushed = 0; o.cap = ~0u; o.aligned4 = true;
+    if (!out) {
+        // the usual case: the segment's bits fit its slot (they do unless a match runs on for more
+        // than ~120 KB past the segment); if not, the stores stop there and the count goes on
+        o.dst = slots + (size_t)k * slot_stride;               // 16-aligned by the host
+        o.head = 0; o.limit = (uint32_t)slot_stride; o.ored = false;
+    } else {
+        // a segment that did not fit: once more, now that its bit offset is known, ORed straight
+        // into the output (into the 256-byte granule its first bit falls in)
+        const unsigned long long g = bit_at[k];
+        o.dst = out + 256ull * (g >> 11);
+        o.head = (uint32_t)(g & 2047ull); o.limit = ~0u; o.ored = true;
+    }
     wg_compress_job(L, job, o);
+}
+
+// Segment k's bits (nbits[k] of them, MSB first from bit 0 of its slot) go to bit bit_at[k] of the
+// stream; the last segment is followed by the end marker 1 1 0000000.  `out` is 4-aligned and
+// zeroed: neighbours share their boundary words, so everything is ORed in.
+__global__ __launch_bounds__(256)
+void lzs_stitch_segments_kernel(uint8_t *__restrict__ out, const uint8_t *__restrict__ slots, size_t slot_stride,
+                                const unsigned long long *__restrict__ bit_at,
+                                const unsigned long long *__restrict__ nbits, uint32_t nseg)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= nseg) return;
+    const unsigned long long at = bit_at[k];
+    const bool fits = nbits[k] <= 8ull * slot_stride;              // else its bits are ORed in directly
+    const uint32_t nb = fits ? (uint32_t)nbits[k] : 0u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(slots + (size_t)k * slot_stride);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(out) + (at >> 5);
+    const uint32_t sh = (uint32_t)(at & 31ull);
+    const uint32_t words = (nb + 31u) >> 5;
+    for (uint32_t j = threadIdx.x; j < words; j += blockDim.x) {
+        uint32_t w = __builtin_bswap32(src[j]);                    // big-endian: stream bit 32j is the MSB
+        if (j == words - 1u && (nb & 31u)) w &= ~0u << (32u - (nb & 31u));
+        const uint32_t hi = w >> sh, lo = sh ? w << (32u - sh) : 0u;
+        if (hi) atomicOr(dst + j, __builtin_bswap32(hi));
+        if (lo) atomicOr(dst + j + 1, __builtin_bswap32(lo));
+    }
+    if (k == nseg - 1u && threadIdx.x == 0) {                      // end marker after the last bit
+        const unsigned long long end = at + nbits[k];
+        const uint32_t s2 = (uint32_t)(end & 31ull);
+        const unsigned long long m = (unsigned long long)0x180u << (64u - 9u - s2);   // 9 bits, left-aligned after s2
+        unsigned int *d2 = reinterpret_cast<unsigned int *>(out) + (end >> 5);
+        atomicOr(d2, __builtin_bswap32((uint32_t)(m >> 32)));
+        if ((uint32_t)m) atomicOr(d2 + 1, __builtin_bswap32((uint32_t)m));
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -2123,15 +2155,27 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
     return launch_decompress(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, stream, 1);
 }
 
-int lzs_hip_launch_compress_segments(void *d_out, const uint64_t *d_bit_at, const void *d_in, uint32_t n,
+int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
-                                     uint32_t *d_keep, void *stream)
+                                     void *d_out, const uint64_t *d_bit_at, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
-                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at, (const uint8_t *)d_in, n, seg, nseg,
-                       d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits, d_keep);
+                       (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
+                       d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
+                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot_stride,
+                                   const uint64_t *d_bit_at, const uint64_t *d_nbits, uint32_t nseg,
+                                   void *stream)
+{
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(lzs_stitch_segments_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, (const uint8_t *)d_slots, slot_stride,
+                       (const unsigned long long *)d_bit_at, (const unsigned long long *)d_nbits, nseg);
     return (int)hipGetLastError();
 }
 
