@@ -51,6 +51,18 @@ int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const vo
 int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot_stride,
                                    const uint64_t *d_bit_at, const uint64_t *d_nbits, uint32_t nseg,
                                    void *stream);
+/* One long stream decompressed by many wavefronts (lzs_scan_stream_kernel, lzs_decode_stream_kernel,
+ * lzs_resolve_stream_kernel; state words and the scheme are described at the kernels). */
+#define LZS_SEG_STOP (1u << 30)
+unsigned lzs_hip_dec_segment_bytes(void);
+int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
+                               const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
+                               uint8_t *d_all_ones /* or NULL */, void *stream);
+int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
+                                 const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
+                                 const uint32_t *d_out_start, void *stream);
+int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
+                                  uint32_t *d_left, void *stream);
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks,
                            void *stream);

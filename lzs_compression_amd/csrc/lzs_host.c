@@ -438,8 +438,155 @@ size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *
     return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
 
+/* lzs_decompress() of one long stream by many wavefronts: see lzs_scan_stream_kernel.  Returns
+ * SIZE_MAX if this path does not apply (output of 4 GiB or more) and the caller should decode
+ * with one wavefront. */
+static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n)
+{
+    const char *who = "lzs_decompress";
+    const uint32_t seg = lzs_hip_dec_segment_bytes();
+    const uint32_t nseg = (uint32_t)((n + seg - 1) / seg);
+    size_t result = 0;
+    int e = 0, rc = LZS_OK;
+    void *d_in = NULL, *d_out = NULL, *d_aux = NULL, *d_origin = NULL;
+    uint32_t *entry = NULL, *exits = NULL, *count = NULL, *start = NULL;
+    uint8_t *dirty = NULL, *ones = NULL;
+    uint32_t *seen = NULL;
+    tls_error[0] = 0;
+    if (require_device() != LZS_OK) goto failed;
+    staging_t *st = staging_get();
+    if (!st) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+    ones = (uint8_t *)malloc(nseg);
+    seen = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+    entry = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+    exits = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+    count = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+    start = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+    dirty = (uint8_t *)malloc(nseg);
+    if (!entry || !exits || !count || !start || !dirty || !ones || !seen) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+
+#define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto failed; } } while (0)
+    if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
+    void *stream = st->stream;
+    const size_t aux_bytes = (size_t)nseg * (4 + 4 + 4 + 4 + 1 + 1) + 128;
+    e = staging_reserve(st, BUF_IN, n + 64, &d_in);
+    if (!e) e = staging_reserve(st, BUF_AUX, aux_bytes, &d_aux);
+    if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+    uint32_t *d_entry = (uint32_t *)d_aux;
+    uint32_t *d_exit = d_entry + nseg;
+    uint32_t *d_count = d_exit + nseg;
+    uint32_t *d_start = d_count + nseg;
+    uint32_t *d_counters = d_start + nseg;                     /* [0] bytes with an origin, [1] left open */
+    uint8_t *d_dirty = (uint8_t *)(d_counters + 2);
+    uint8_t *d_ones = d_dirty + nseg;
+
+    const int debug = getenv("LZS_STREAM_DEBUG") != NULL;
+    double t0 = debug ? now_ms() : 0, t1;
+    HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
+    /* SCAN rounds: every segment entered at its first bit in the normal state, then corrected */
+    for (uint32_t k = 0; k < nseg; k++) { entry[k] = 0; dirty[k] = 1; seen[k] = 0xFFFFFFFFu; }
+    for (uint32_t round = 0, ndirty = nseg; ndirty; round++) {
+        HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
+                                           round == 0 ? d_ones : NULL, stream), who);
+        HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        const uint32_t was = ndirty;
+        for (uint32_t k = 0; k < nseg; k++) if (dirty[k]) seen[k] = entry[k];   /* exits[k], count[k] belong to this entry */
+        ndirty = 0;
+        dirty[0] = 0;
+        int ended = 0;
+        int settled = 1;            /* every segment before k has been walked from its final entry */
+        for (uint32_t k = 1; k < nseg; k++) {
+            uint32_t want = exits[k - 1];
+            if (want & LZS_SEG_STOP) {
+                /* end marker or end of input before k -- believed only from a settled walk: one that
+                 * was entered at a guessed bit reads end markers into the data now and then */
+                if (settled) ended = 1; else want = entry[k];
+            }
+            if (ended) want = LZS_SEG_STOP;
+            if (want != entry[k]) settled = 0;
+            entry[k] = want;
+            dirty[k] = 0;
+            /* a segment behind the (current) end of the stream keeps what it reported for its last
+             * entry: the end may turn out to be a misread of a walk that had not fallen in step */
+            if (ended || want == seen[k]) continue;
+            if (((want >> 8) & 1u) && ones[k]) {
+                /* all 0xFF inside a running extension: 65536 nibbles of 15, leaves as it was entered
+                 * (the segment length in bits is a multiple of 4); no need to walk it */
+                exits[k] = want;
+                count[k] = 15u * (seg * 8u / 4u);
+                seen[k] = want;
+                continue;
+            }
+            dirty[k] = 1;
+            ndirty++;
+        }
+        /* what the host worked out itself must survive the next round's copy back */
+        if (ndirty) {
+            HIP_TRY(lzs_hip_h2d(d_exit, exits, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_h2d(d_count, count, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        }
+        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: round %u scanned %u of %u segments in %.2f ms; %u to redo\n", round, was, nseg, t1 - t0, ndirty); t0 = t1; }
+    }
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < nseg; k++) {
+        start[k] = (uint32_t)total;
+        if (!(entry[k] & LZS_SEG_STOP)) total += count[k];
+        if (total >= 0xFFFFFF00ull - 0x100000ull) break;
+    }
+    if (total >= 0xFFFFFF00ull - 0x100000ull) { result = SIZE_MAX; goto done; }   /* positions are 32-bit here */
+    const uint32_t produce = (uint32_t)(total < cap ? total : cap);
+    if (produce) {
+        e = staging_reserve(st, BUF_OUT, (size_t)produce + 64, &d_out);
+        if (!e) e = staging_reserve(st, BUF_KEEP, 4 * (size_t)produce + 64, &d_origin);
+        if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+        HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
+        HIP_TRY(lzs_hip_launch_decode_stream(d_out, produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
+                                             nseg, d_entry, d_start, stream), who);
+        uint32_t open[2] = {0, 0};
+        HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: %u bytes decoded in %.2f ms, %u with an origin in another segment\n", produce, t1 - t0, open[0]); t0 = t1; }
+        uint32_t left = open[0];
+        for (uint32_t round = 1; left && round < 250; round++) {
+            HIP_TRY(lzs_hip_memset(d_counters + 1, 0, 4, stream), "hipMemset");
+            HIP_TRY(lzs_hip_launch_resolve_stream(d_out, (uint32_t *)d_origin, produce, round, d_counters + 1, stream), who);
+            HIP_TRY(lzs_hip_d2h(&left, d_counters + 1, 4, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+            if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: resolve round %u in %.2f ms, %u left\n", round, t1 - t0, left); t0 = t1; }
+        }
+        if (left) { fail(LZS_E_HIP, "%s: origins did not resolve", who); goto failed; }
+        HIP_TRY(lzs_hip_d2h(out, d_out, produce, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    }
+    result = produce;
+#undef HIP_TRY
+    goto done;
+
+failed:
+    result = 0;
+    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+    { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
+done:
+    free(entry); free(exits); free(count); free(start); free(dirty); free(ones); free(seen);
+    { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
+    (void)rc;
+    return result;
+}
+
 size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
+    if (a_inLen > 262144u && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && a_outBufferSize &&
+        !getenv("LZS_ONE_WAVE")) {
+        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+        if (got != SIZE_MAX) return got;
+    }
     return one_shot("lzs_decompress", lzs_hip_launch_decompress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
 

@@ -1996,6 +1996,263 @@ void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_strid
 }
 
 // ---------------------------------------------------------------------------------
+// ONE long stream decompressed by many wavefronts (the counterpart of the segment compressor).
+// The compressed stream is cut into segments of kDecSeg bytes, one wave each.  What a segment
+// cannot know by itself is the decoder's state when its bit cursor first crosses into it: the bit
+// where the first token starts, whether an extension is running and at which offset.  So:
+//   SCAN    every segment walks its tokens without copying anything, entered at its first bit in
+//           the normal state, and reports the state in which it leaves and how many bytes it
+//           would produce; the host re-runs the segments whose predecessor left in another state
+//           until all agree (walks entered at different bits fall in step after some tokens), and
+//           takes the prefix sum of the byte counts;
+//   DECODE  every segment decodes into the output at its offset.  A copy whose source lies before
+//           the segment's own output cannot be done yet -- that part of the output is being
+//           produced by another wave -- so every byte carries an ORIGIN: clean, or the output
+//           position it is a copy of.  Origins are copied along with the bytes;
+//   RESOLVE rounds of pointer jumping over the origins (a byte whose origin is clean takes its
+//           value, otherwise it adopts its origin's origin) until none is left.
+// Stop rules as in lzs_decompress_blocks_v2_kernel, one-shot form (the first end marker ends it).
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kDecSeg   = 8192;                  // compressed bytes per segment (a wave walks it in ~1 ms)
+constexpr uint32_t kDecEnd   = 8u * kDecSeg;          // its length in bits
+constexpr uint32_t kClean    = 0xFFFFFFFFu;           // origin: the byte is final
+constexpr uint32_t kDoneBase = 0xFFFFFF00u;           // origin: resolved in round (value & 0xFF)
+constexpr uint32_t kSegStop  = 1u << 30;              // state word: the stream ended in this segment
+// state word: bits 0..7 cursor past the segment start (bits), bit 8 extension running, 9..19 offset
+
+struct DecSegLds {
+    uint32_t ring[kRingWords];                        // the segment's own output window
+    uint32_t origin[kRingWords * 4];                  // per byte of it
+};
+
+template <bool DECODE>
+__device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ in, uint32_t n, uint32_t k, uint32_t entry,
+                                                   uint32_t *exit_out, uint32_t *count_out,
+                                                   uint8_t *out, uint32_t cap, uint32_t out_start,
+                                                   uint32_t *origin_g, uint32_t *tainted_total,
+                                                   DecSegLds *Lp, uint32_t lane)
+{
+    uint8_t *ring8 = DECODE ? reinterpret_cast<uint8_t *>(Lp->ring) : nullptr;
+    uint32_t *origin = DECODE ? Lp->origin : nullptr;
+    const uint32_t rel0 = entry & 0xFFu;
+    const uint32_t byte0 = kDecSeg * k + (rel0 >> 3);
+    uint32_t count = 0, flushed = 0, tainted = 0;
+    uint32_t off = (entry >> 9) & 0x7FFu;
+    uint32_t extended = (entry >> 8) & 1u;
+    uint32_t state = kSegStop;
+    if (byte0 < n) {
+        const uint8_t *src = in + byte0;
+        const uint32_t nn = n - byte0;
+        // the input as aligned words (as in lzs_decompress_blocks_v2_kernel)
+        const uint32_t skew = (uint32_t)((uintptr_t)src & 3u);
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(src - skew);
+        const uint32_t nwords = (skew + nn + 3u) >> 2;
+        uint64_t bits; uint32_t have, pos, wi = 1, nextw = 0;
+        {
+            uint32_t w = __builtin_bswap32(w32[0]) << (8u * skew);
+            const uint32_t avail = 4u - skew < nn ? 4u - skew : nn;
+            if (avail < 4u) w &= ~0u << (32u - 8u * avail);
+            bits = (uint64_t)w << 32; have = 8u * avail; pos = avail;
+            if (nwords > 1u) nextw = w32[1];
+        }
+        bits <<= rel0 & 7u; have -= rel0 & 7u;                   // the first token starts inside the byte
+        const uint32_t base = 8u * (rel0 >> 3);
+        for (;;) {
+            if (have <= 32u) {
+                if (pos < nn) {
+                    uint32_t w = __builtin_bswap32(nextw);
+                    const uint32_t rem = nn - pos;
+                    const uint32_t nb = rem < 4u ? rem : 4u;
+                    if (rem < 4u) w &= ~0u << (32u - 8u * rem);
+                    bits |= (uint64_t)w << (32u - have);
+                    have += 8u * nb; pos += nb; wi += 1u;
+                    if (wi < nwords) nextw = w32[wi];
+                }
+            }
+            const uint32_t cur = base + 8u * pos - have;         // bits past the segment start
+            if (cur >= kDecEnd) {                                // the next token belongs to the next segment
+                // (the offset is part of the state only while an extension runs: otherwise two walks
+                // that fell in step would still look different to the host)
+                state = (cur - kDecEnd) | (extended << 8) | ((extended ? off : 0u) << 9);
+                break;
+            }
+            if (have == 0u) break;                               // input exhausted (:189)
+            if (DECODE && out_start + count >= cap) break;       // output full (:200)
+            uint32_t copy_len = 0;
+            const uint32_t top = (uint32_t)(bits >> 32);
+            if (extended) {                                      // :370-406
+                if (have < 4u) break;
+                // nibbles of 15 (a long match is thousands of them) go up to four at a time: 60 bytes
+                const uint32_t ones = (~bits ? (uint32_t)__builtin_clzll(~bits) : 64u) >> 2;   // leading 1111 nibbles
+                uint32_t run = ones < have / 4u ? ones : have / 4u;
+                const uint32_t mine = (kDecEnd - cur + 3u) / 4u;                // nibbles that start in this segment
+                run = run < mine ? run : mine;
+                run = run < 4u ? run : 4u;
+                if (run) {
+                    copy_len = kNibbleMax * run;
+                    bits <<= 4u * run; have -= 4u * run;
+                } else {
+                    copy_len = top >> 28;                        // the closing nibble, 0..14
+                    bits <<= 4; have -= 4u;
+                    extended = 0;
+                }
+            } else if ((int32_t)top >= 0) {
+                // a run of literals, but only those that start inside this segment
+                if (have < 9u) break;
+                const uint64_t types = bits & 0x8040201008040200ull;
+                uint32_t kk = (types ? (uint32_t)__builtin_clzll(types) : 64u) / 9u;
+                const uint32_t fit = have / 9u;
+                const uint32_t mine = (kDecEnd - cur + 8u) / 9u;
+                kk = kk < fit ? kk : fit;
+                kk = kk < mine ? kk : mine;
+                if (DECODE) {
+                    if (lane < kk) {
+                        const uint32_t at = (count + lane) & kRingMask;
+                        ring8[at] = (uint8_t)(bits >> (55u - 9u * lane));
+                        origin[at] = kClean;
+                    }
+                }
+                count += kk;
+                bits <<= 9u * kk; have -= 9u * kk;
+            } else {
+                const uint32_t t = top >> 11;                    // 1 s ooooooo[oooo] cccc
+                const bool is_short = (t >> 19) & 1u;
+                const uint32_t o = is_short ? (t >> 12) & 0x7Fu : (t >> 8) & 0x7FFu;
+                const uint32_t used = is_short ? 9u : 13u;
+                if (o == 0u) {
+                    if (have < used) break;
+                    bits <<= used; have -= used;
+                    if (is_short) break;                         // end marker: the stream ends here
+                    off = 0;                                     // long offset 0: no copy (:280)
+                    continue;
+                }
+                const uint32_t code = (is_short ? t >> 8 : t >> 4) & 0xFu;
+                const uint32_t len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
+                const uint32_t width = code < 0xCu ? 2u : 4u;
+                if (have < used + width) break;
+                bits <<= used + width; have -= used + width;
+                off = o;
+                extended = len == kTokenMax ? 1u : 0u;
+                copy_len = len;
+            }
+            if (copy_len) {
+                if (DECODE) {
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t v = 0, og = kClean;
+                    if (lane < copy_len) {
+                        // overlap replicates with period `off` (copy_len <= 60)
+                        const uint32_t kk = off >= 60u ? lane : (off ? lane % off : 0u);
+                        const uint32_t from = count + kk;        // position + off of the source
+                        if (from >= off) {                       // inside this segment's own output
+                            const uint32_t at = (from - off) & kRingMask;
+                            v = ring8[at]; og = origin[at];
+                        } else if ((unsigned long long)out_start + from >= off) {
+                            og = out_start + from - off;         // produced by another wave: by position
+                        }                                        // else before out[0]: zero (:350-357)
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < copy_len) {
+                        const uint32_t at = (count + lane) & kRingMask;
+                        ring8[at] = (uint8_t)v; origin[at] = og;
+                    }
+                }
+                count += copy_len;
+            }
+            if (DECODE) {
+                if (count - flushed >= kTile) {                  // a finished KiB goes out
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t j = 0; j < kTile; j += 64u) {
+                        const uint32_t p = flushed + j + lane;
+                        const uint32_t g = out_start + p;
+                        const uint32_t og = origin[p & kRingMask];
+                        if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og; tainted += og != kClean; }
+                    }
+                    flushed += kTile;
+                }
+            }
+        }
+    }
+    if (DECODE) {
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t p = flushed + lane; p < count; p += 64u) {
+            const uint32_t g = out_start + p;
+            const uint32_t og = origin[p & kRingMask];
+            if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og; tainted += og != kClean; }
+        }
+        if (tainted) atomicAdd(tainted_total, tainted);
+    } else if (lane == 0) {
+        *exit_out = state;
+        *count_out = count;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
+                            const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
+                            uint32_t *__restrict__ exit_state, uint32_t *__restrict__ count,
+                            uint8_t *__restrict__ all_ones)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + uniform(threadIdx.x >> 6);
+    if (k >= nseg) return;
+    if (all_ones) {
+        // A whole segment of 0xFF bytes inside a running extension is nothing but nibbles of 15:
+        // it leaves in the state in which it was entered.  The host uses this to carry a long
+        // match across its segments without a round each.
+        bool ones = (size_t)(k + 1u) * kDecSeg <= n;
+        if (ones) {
+            const uint8_t *p = in + (size_t)k * kDecSeg;
+            for (uint32_t i = lane; i < kDecSeg && ones; i += 64u) ones = p[i] == 0xFFu;
+        }
+        const bool all = __builtin_amdgcn_ballot_w64(!ones) == 0ull;
+        if (lane == 0) all_ones[k] = all;
+    }
+    if (dirty && !dirty[k]) return;
+    lzs_stream_segment<false>(in, n, k, uniform(entry[k]), exit_state + k, count + k,
+                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane);
+}
+
+__global__ __launch_bounds__(128)
+void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t *__restrict__ origin_g,
+                              uint32_t *__restrict__ tainted_total,
+                              const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
+                              const uint32_t *__restrict__ entry, const uint32_t *__restrict__ out_start)
+{
+    __shared__ DecSegLds lds[2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = uniform(threadIdx.x >> 6);
+    const uint32_t k = blockIdx.x * 2u + wv;
+    if (k >= nseg) return;
+    const uint32_t e = uniform(entry[k]);
+    if (e & kSegStop) return;                                 // the stream ended before this segment
+    lzs_stream_segment<true>(in, n, k, e, nullptr, nullptr, out, cap, uniform(out_start[k]),
+                             origin_g, tainted_total, &lds[wv], lane);
+}
+
+// One round of pointer jumping over the origins (each launch only trusts what earlier launches
+// finished: a byte resolved in this round is marked with the round number and becomes a source in
+// the next one).  `left` counts the bytes still open after the round.
+__global__ __launch_bounds__(256)
+void lzs_resolve_stream_kernel(uint8_t *__restrict__ out, uint32_t *__restrict__ origin_g, uint32_t total,
+                               uint32_t round, uint32_t *__restrict__ left)
+{
+    uint32_t open = 0;
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < total; p += gridDim.x * 256u) {
+        const uint32_t o = origin_g[p];
+        if (o >= kDoneBase) continue;                             // final, or resolved earlier
+        const uint32_t oo = origin_g[o];
+        if (oo == kClean || (oo >= kDoneBase && (oo & 0xFFu) < round)) {
+            out[p] = out[o];
+            origin_g[p] = kDoneBase | round;
+        } else {
+            if (oo < kDoneBase) origin_g[p] = oo;                 // adopt the origin's origin
+            open++;
+        }
+    }
+    if (open) atomicAdd(left, open);
+}
+
+// ---------------------------------------------------------------------------------
 // Compaction of fixed-stride slots into one dense string.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
@@ -2178,6 +2435,39 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
                        (const unsigned long long *)d_bit_at, (const unsigned long long *)d_nbits, nseg);
     return (int)hipGetLastError();
 }
+
+int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
+                               const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
+                               uint8_t *d_all_ones, void *stream)
+{
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
+                                 const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
+                                 const uint32_t *d_out_start, void *stream)
+{
+    if (nseg == 0) return 0;
+    hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 1) / 2), dim3(128), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
+                                  uint32_t *d_left, void *stream)
+{
+    if (total == 0) return 0;
+    uint32_t grid = (total + 255u) / 256u;
+    if (grid > 65536u) grid = 65536u;
+    hipLaunchKernelGGL(lzs_resolve_stream_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, d_origin, total, round, d_left);
+    return (int)hipGetLastError();
+}
+
+unsigned lzs_hip_dec_segment_bytes(void) { return kDecSeg; }
 
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks, void *stream)

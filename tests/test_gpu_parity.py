@@ -416,6 +416,46 @@ def test_stream_device_entry_point_1gib_text():
     assert 0.5 < nbytes / x.numel() < 0.6
 
 
+def test_one_long_stream_decompressed_by_many_wavefronts():
+    """lzs_decompress() of a stream longer than 256 KiB is cut into 8 KiB segments, one wavefront
+    each: the segments agree on the decoder state at their borders in a few rounds, decode with
+    per-byte origins for copies that reach into another segment's output, and resolve those by
+    pointer jumping.  Same bytes and the same stop rules as one wavefront: every class, a mixture
+    with runs and repeats over many segments, a cut capacity, garbage, a stream without end marker
+    and one with data after the end marker."""
+    rng = np.random.default_rng(77)
+    datas = []
+    for cls in workload.CLASS_NAMES:
+        datas.append(bytes(workload.fill(cls, 100).reshape(-1)[: 100 * 65536 - 4321]))
+    mix = bytearray()
+    text = bytes(workload.fill("text", 8).reshape(-1))
+    while len(mix) < 9_000_000:
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            mix += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 400_000))
+        elif k == 1:
+            a = int(rng.integers(0, len(text) - 1)); mix += text[a: a + int(rng.integers(1, 150_000))]
+        elif k == 2:
+            mix += bytes(rng.integers(0, 256, int(rng.integers(1, 70_000)), dtype=np.uint8))
+        else:
+            unit = bytes(rng.integers(0, 256, int(rng.integers(2, 2500)), dtype=np.uint8))
+            mix += unit * int(rng.integers(1, 300))
+    datas.append(bytes(mix))
+    for d in datas:
+        comp = O.compress(d)
+        assert len(comp) > 262144 or d is datas[1]            # (the low-entropy class may stay below the threshold)
+        assert lzs.decompress(comp, len(d) + 5) == d
+        assert lzs.decompress(comp, len(d) // 3) == d[: len(d) // 3]
+        assert lzs.decompress(comp[: len(comp) // 2], len(d)) == O.decompress(comp[: len(comp) // 2], len(d))
+        assert lzs.decompress(comp + comp[:5000], len(d) + 5) == d     # the first end marker ends it
+    for _ in range(3):                                        # garbage: same result as the serial rules
+        junk = bytes(rng.integers(0, 256, int(rng.integers(300_000, 900_000)), dtype=np.uint8))
+        for cap in (1000, 4_000_000):
+            assert lzs.decompress(junk, cap) == O.decompress(junk, cap)
+    ones = bytes([0xFF]) * 400_000                            # an endless extension (offset 127)
+    assert lzs.decompress(ones, 3_000_000) == O.decompress(ones, 3_000_000)
+
+
 @pytest.mark.parametrize("variant", ["chain", "scan"])
 def test_other_kernel_variants_agree(variant):
     """The A/B variants (LZS_KERNEL=chain|scan) produce the same bytes as the default kernel."""
