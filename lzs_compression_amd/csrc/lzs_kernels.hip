@@ -2020,9 +2020,11 @@ constexpr uint32_t kDoneBase = 0xFFFFFF00u;           // origin: resolved in rou
 constexpr uint32_t kSegStop  = 1u << 30;              // state word: the stream ended in this segment
 // state word: bits 0..7 cursor past the segment start (bits), bit 8 extension running, 9..19 offset
 
+// In LDS an origin is how far BEFORE the segment's output it lies (1..2047: a copy can only reach
+// that far, and copies of copies inherit it), 0 = clean: 16 bits per byte of the window.
 struct DecSegLds {
     uint32_t ring[kRingWords];                        // the segment's own output window
-    uint32_t origin[kRingWords * 4];                  // per byte of it
+    uint16_t origin[kRingWords * 4];                  // per byte of it
 };
 
 template <bool DECODE>
@@ -2033,7 +2035,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                                                    DecSegLds *Lp, uint32_t lane)
 {
     uint8_t *ring8 = DECODE ? reinterpret_cast<uint8_t *>(Lp->ring) : nullptr;
-    uint32_t *origin = DECODE ? Lp->origin : nullptr;
+    uint16_t *origin = DECODE ? Lp->origin : nullptr;
     const uint32_t rel0 = entry & 0xFFu;
     const uint32_t byte0 = kDecSeg * k + (rel0 >> 3);
     uint32_t count = 0, flushed = 0, tainted = 0;
@@ -2109,7 +2111,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                     if (lane < kk) {
                         const uint32_t at = (count + lane) & kRingMask;
                         ring8[at] = (uint8_t)(bits >> (55u - 9u * lane));
-                        origin[at] = kClean;
+                        origin[at] = 0;
                     }
                 }
                 count += kk;
@@ -2138,7 +2140,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
             if (copy_len) {
                 if (DECODE) {
                     __builtin_amdgcn_wave_barrier();
-                    uint32_t v = 0, og = kClean;
+                    uint32_t v = 0, og = 0;
                     if (lane < copy_len) {
                         // overlap replicates with period `off` (copy_len <= 60)
                         const uint32_t kk = off >= 60u ? lane : (off ? lane % off : 0u);
@@ -2147,13 +2149,13 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                             const uint32_t at = (from - off) & kRingMask;
                             v = ring8[at]; og = origin[at];
                         } else if ((unsigned long long)out_start + from >= off) {
-                            og = out_start + from - off;         // produced by another wave: by position
+                            og = off - from;                     // produced by another wave: that far before my output
                         }                                        // else before out[0]: zero (:350-357)
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (lane < copy_len) {
                         const uint32_t at = (count + lane) & kRingMask;
-                        ring8[at] = (uint8_t)v; origin[at] = og;
+                        ring8[at] = (uint8_t)v; origin[at] = (uint16_t)og;
                     }
                 }
                 count += copy_len;
@@ -2165,7 +2167,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                         const uint32_t p = flushed + j + lane;
                         const uint32_t g = out_start + p;
                         const uint32_t og = origin[p & kRingMask];
-                        if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og; tainted += og != kClean; }
+                        if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og ? out_start - og : kClean; tainted += og != 0u; }
                     }
                     flushed += kTile;
                 }
@@ -2177,7 +2179,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
         for (uint32_t p = flushed + lane; p < count; p += 64u) {
             const uint32_t g = out_start + p;
             const uint32_t og = origin[p & kRingMask];
-            if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og; tainted += og != kClean; }
+            if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og ? out_start - og : kClean; tainted += og != 0u; }
         }
         if (tainted) atomicAdd(tainted_total, tainted);
     } else if (lane == 0) {
@@ -2212,16 +2214,16 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
                               nullptr, 0, 0, nullptr, nullptr, nullptr, lane);
 }
 
-__global__ __launch_bounds__(128)
+__global__ __launch_bounds__(256)
 void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t *__restrict__ origin_g,
                               uint32_t *__restrict__ tainted_total,
                               const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
                               const uint32_t *__restrict__ entry, const uint32_t *__restrict__ out_start)
 {
-    __shared__ DecSegLds lds[2];
+    __shared__ DecSegLds lds[4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = uniform(threadIdx.x >> 6);
-    const uint32_t k = blockIdx.x * 2u + wv;
+    const uint32_t k = blockIdx.x * 4u + wv;
     if (k >= nseg) return;
     const uint32_t e = uniform(entry[k]);
     if (e & kSegStop) return;                                 // the stream ended before this segment
@@ -2451,7 +2453,7 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
                                  const uint32_t *d_out_start, void *stream)
 {
     if (nseg == 0) return 0;
-    hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 1) / 2), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start);
     return (int)hipGetLastError();
 }
