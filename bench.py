@@ -214,6 +214,13 @@ def main() -> None:
                 result["single_stream"] = {"entry": "lzs_compress_stream_device", "input_bytes": int(flat.numel()),
                                            "compressed_bytes": nbytes, "ms": dt * 1e3,
                                            "value": flat.numel() / dt / 1e9, "unit": "GB/s"}
+                back, got = lzs.decompress_stream(buf[:nbytes], flat.numel() + 16)
+                t = time.perf_counter()
+                back, got = lzs.decompress_stream(buf[:nbytes], flat.numel() + 16, back)
+                dt = time.perf_counter() - t
+                result["single_stream"]["decompress"] = {
+                    "entry": "lzs_decompress_stream_device", "ms": dt * 1e3, "value": got / dt / 1e9,
+                    "unit": "GB/s of output", "round_trip": bool(got == flat.numel() and torch.equal(back[:got], flat))}
             except Exception as exc:                      # never let the extra line spoil the contract line
                 result["single_stream"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:

@@ -84,6 +84,18 @@ int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
                                const void *d_in, size_t in_len);
 
 /*
+ * The reverse: ONE stream in device memory decompressed by many wavefronts -- the result of
+ * lzs_decompress(d_out, out_cap, d_in, in_len) (reference lzs-decompression.c:156-412: stops at
+ * the first end marker, at out_cap, or when the bits run out).  The stream is cut into 8 KiB
+ * segments that agree on the decoder state at their borders in a few rounds, decode with per-byte
+ * origins for copies reaching into another segment's output, and resolve those by pointer jumping
+ * (DESIGN.md 3.6).  The 4-argument lzs_decompress() takes the same route above 256 KiB.  Output
+ * below 4 GiB; allocates 4 * produced bytes of scratch on this thread's staging; synchronous.
+ */
+int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
+                                 const void *d_in, size_t in_len);
+
+/*
  * Gather the variable-length results of a batch into one dense byte string:
  * d_offsets[b] = sum of d_len[0..b) for b = 0..nblocks (nblocks+1 entries, uint64),
  * d_dense[d_offsets[b] .. d_offsets[b+1]) = slot b's first d_len[b] bytes.

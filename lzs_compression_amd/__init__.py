@@ -7,9 +7,9 @@ fallback: without the built library or without a GPU, calls raise.
 """
 from .api import (LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
                   compress_stream, compressed_max, decompress, decompress_batch, decompress_blocks, decompress_concat,
-                  decompressed_max, last_error, lib)
+                  decompress_stream, decompressed_max, last_error, lib)
 from . import workload
 
 __all__ = ["LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
            "compress_stream", "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_concat",
-           "decompressed_max", "last_error", "lib", "workload"]
+           "decompress_stream", "decompressed_max", "last_error", "lib", "workload"]

@@ -68,6 +68,8 @@ def lib() -> ctypes.CDLL:
             f.restype, f.argtypes = ctypes.c_int, _BATCH_HOST
         L.lzs_compress_stream_device.restype = ctypes.c_int
         L.lzs_compress_stream_device.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _vp, _sz]
+        L.lzs_decompress_stream_device.restype = ctypes.c_int
+        L.lzs_decompress_stream_device.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _vp, _sz]
         L.lzs_compact_device.restype = ctypes.c_int
         L.lzs_compact_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
         _lib = L
@@ -206,6 +208,17 @@ def compress_stream(x, out=None):
         out = torch.empty(need, dtype=torch.uint8, device=x.device)
     got = _sz(0)
     _check(lib().lzs_compress_stream_device(out.data_ptr(), out.numel(), ctypes.byref(got), x.data_ptr(), n))
+    return out, int(got.value)
+
+
+def decompress_stream(x, out_capacity, out=None):
+    """lzs_decompress_stream_device(): the device tensor ``x`` (one LZS stream, uint8) decompressed
+    by many wavefronts.  Returns (buffer uint8 [out_capacity], nbytes).  Synchronous."""
+    import torch
+    if out is None:
+        out = torch.empty(out_capacity, dtype=torch.uint8, device=x.device)
+    got = _sz(0)
+    _check(lib().lzs_decompress_stream_device(out.data_ptr(), out_capacity, ctypes.byref(got), x.data_ptr(), x.numel()))
     return out, int(got.value)
 
 

@@ -441,9 +441,9 @@ size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *
 /* lzs_decompress() of one long stream by many wavefronts: see lzs_scan_stream_kernel.  Returns
  * SIZE_MAX if this path does not apply (output of 4 GiB or more) and the caller should decode
  * with one wavefront. */
-static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n)
+static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status)
 {
-    const char *who = "lzs_decompress";
+    const char *who = dev ? "lzs_decompress_stream_device" : "lzs_decompress";
     const uint32_t seg = lzs_hip_dec_segment_bytes();
     const uint32_t nseg = (uint32_t)((n + seg - 1) / seg);
     size_t result = 0;
@@ -469,7 +469,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
     if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
     void *stream = st->stream;
     const size_t aux_bytes = (size_t)nseg * (4 + 4 + 4 + 4 + 1 + 1) + 128;
-    e = staging_reserve(st, BUF_IN, n + 64, &d_in);
+    if (dev) d_in = (void *)in; else e = staging_reserve(st, BUF_IN, n + 64, &d_in);
     if (!e) e = staging_reserve(st, BUF_AUX, aux_bytes, &d_aux);
     if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
     uint32_t *d_entry = (uint32_t *)d_aux;
@@ -482,7 +482,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
 
     const int debug = getenv("LZS_STREAM_DEBUG") != NULL;
     double t0 = debug ? now_ms() : 0, t1;
-    HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
+    if (!dev) HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
     /* SCAN rounds: every segment entered at its first bit in the normal state, then corrected */
     for (uint32_t k = 0; k < nseg; k++) { entry[k] = 0; dirty[k] = 1; seen[k] = 0xFFFFFFFFu; }
     for (uint32_t round = 0, ndirty = nseg; ndirty; round++) {
@@ -541,7 +541,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
     if (total >= 0xFFFFFF00ull - 0x100000ull) { result = SIZE_MAX; goto done; }   /* positions are 32-bit here */
     const uint32_t produce = (uint32_t)(total < cap ? total : cap);
     if (produce) {
-        e = staging_reserve(st, BUF_OUT, (size_t)produce + 64, &d_out);
+        if (dev) d_out = out; else e = staging_reserve(st, BUF_OUT, (size_t)produce + 64, &d_out);
         if (!e) e = staging_reserve(st, BUF_KEEP, 4 * (size_t)produce + 64, &d_origin);
         if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
@@ -562,7 +562,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
             if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: resolve round %u in %.2f ms, %u left\n", round, t1 - t0, left); t0 = t1; }
         }
         if (left) { fail(LZS_E_HIP, "%s: origins did not resolve", who); goto failed; }
-        HIP_TRY(lzs_hip_d2h(out, d_out, produce, stream), "hipMemcpy D2H");
+        if (!dev) HIP_TRY(lzs_hip_d2h(out, d_out, produce, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
     }
     result = produce;
@@ -571,20 +571,35 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
 
 failed:
     result = 0;
-    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+    if (rc == LZS_OK) rc = LZS_E_HIP;
+    if (!dev) fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
 done:
     free(entry); free(exits); free(count); free(start); free(dirty); free(ones); free(seen);
     { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
-    (void)rc;
+    if (status) *status = rc;
     return result;
+}
+
+int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len, const void *d_in, size_t in_len)
+{
+    if (!out_len) return fail(LZS_E_ARG, "lzs_decompress_stream_device: out_len is NULL");
+    *out_len = 0;
+    if ((!d_out && out_cap) || (!d_in && in_len)) return fail(LZS_E_ARG, "lzs_decompress_stream_device: NULL buffer");
+    if (in_len == 0 || out_cap == 0) return LZS_OK;
+    if (in_len > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "lzs_decompress_stream_device: stream exceeds LZS_BLOCK_MAX");
+    int rc = LZS_OK;
+    const size_t got = stream_decompress((uint8_t *)d_out, out_cap, (const uint8_t *)d_in, in_len, 1, &rc);
+    if (got == SIZE_MAX) return fail(LZS_E_ARG, "lzs_decompress_stream_device: output of 4 GiB or more");
+    *out_len = got;
+    return rc;
 }
 
 size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
     if (a_inLen > 262144u && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && a_outBufferSize &&
         !getenv("LZS_ONE_WAVE")) {
-        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
         if (got != SIZE_MAX) return got;
     }
     return one_shot("lzs_decompress", lzs_hip_launch_decompress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);

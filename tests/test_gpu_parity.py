@@ -414,6 +414,9 @@ def test_stream_device_entry_point_1gib_text():
     keep = len(want) - 64
     assert got[:keep] == want[:keep]
     assert 0.5 < nbytes / x.numel() < 0.6
+    # and back, still on the device: the stream decompressed by many wavefronts is the input
+    back, n = lzs.decompress_stream(out[:nbytes], x.numel() + 16)
+    assert n == x.numel() and torch.equal(back[:n], x.reshape(-1))
 
 
 def test_one_long_stream_decompressed_by_many_wavefronts():
