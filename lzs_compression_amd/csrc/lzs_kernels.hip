@@ -1836,8 +1836,9 @@ void lzs_decompress_blocks_kernel(uint8_t *__restrict__ out, size_t out_stride, 
 // instructions per output byte and saturated the CU's one scalar unit (rocprofv3: 3.1e10 SALU per
 // GiB = 93 % of its issue slots) -- its compressed input went HBM -> LDS tile -> ds_read ->
 // v_readfirstlane, and its conditions were combined as lane masks.  Here the compressed stream is
-// read straight into scalar registers (s_load_dword, one word ahead of use, no LDS tile), and the
-// token decode is nested single compares.
+// read by plain word loads one word ahead of use (no LDS tile), the token decode is nested single
+// compares, and the fields of a match token are extracted on the (idle) vector unit and come back
+// packed through one v_readfirstlane.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWavesPerWG * 64)
 void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_stride, uint32_t out_cap,
@@ -1916,12 +1917,15 @@ void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_strid
             // a run of literals (:217-233), up to 7 at once: token i of an all-literal run starts
             // at bit 63 - 9i, so the first set type bit among those tells how long the run is
             if (have < 9u) break;                                  // type bit, then 8 more or stop (:220-223)
-            const uint64_t types = bits & 0x8040201008040200ull;
-            uint32_t k = (types ? (uint32_t)__builtin_clzll(types) : 64u) / 9u;
-            const uint32_t fit = have / 9u;
-            k = k < fit ? k : fit;
-            k = k < room ? k : room;
-            if (lane < k) ring8[(count + lane) & kRingMask] = (uint8_t)(bits >> (55u - 9u * lane));
+            // (counted on the vector unit, like the match fields below)
+            const uint32_t th = opaque(top) & 0x80402010u, tl = opaque((uint32_t)bits) & 0x08040200u;
+            const uint32_t lead = th ? (uint32_t)__builtin_clz(th) : (tl ? 32u + (uint32_t)__builtin_clz(tl) : 64u);
+            uint32_t kv = (lead * 57u) >> 9;                       // lead / 9 for lead <= 64
+            const uint32_t fitv = (opaque(have) * 57u) >> 9;       // have / 9 for have <= 64
+            kv = kv < fitv ? kv : fitv;
+            kv = kv < room ? kv : room;
+            const uint32_t k = uniform(kv);
+            if (lane < kv) ring8[(count + lane) & kRingMask] = (uint8_t)(bits >> (55u - 9u * lane));
             count += k;
             bits <<= 9u * k; have -= 9u * k;
         } else {
@@ -1931,10 +1935,19 @@ void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_strid
             // because a token produces nothing before its last field is read, and bits can only
             // be missing when the input is exhausted (the refill above keeps more than a token's
             // worth otherwise).
-            const uint32_t t = top >> 11;
-            const bool is_short = (t >> 19) & 1u;
-            const uint32_t o = is_short ? (t >> 12) & 0x7Fu : (t >> 8) & 0x7FFu;
-            const uint32_t used = is_short ? 9u : 13u;
+            // field extraction on the vector unit (the scalar unit is the bottleneck): the values
+            // are the same in every lane and come back through v_readfirstlane
+            const uint32_t t = opaque(top) >> 11;
+            const bool is_short_v = (t >> 19) & 1u;
+            const uint32_t o_v = is_short_v ? (t >> 12) & 0x7Fu : (t >> 8) & 0x7FFu;
+            const uint32_t used_v = is_short_v ? 9u : 13u;
+            const uint32_t code_v = (is_short_v ? t >> 8 : t >> 4) & 0xFu;
+            const uint32_t len_v = code_v < 0xCu ? 2u + (code_v >> 2) : code_v - 7u;
+            const uint32_t width_v = code_v < 0xCu ? 2u : 4u;
+            // packed: o (11) | used (4) << 11 | len (4) << 15 | width (3) << 19 | is_short << 22
+            const uint32_t packed = uniform(o_v | (used_v << 11) | (len_v << 15) | (width_v << 19) | ((is_short_v ? 1u : 0u) << 22));
+            const uint32_t o = packed & 0x7FFu, used = (packed >> 11) & 15u;
+            const bool is_short = (packed >> 22) & 1u;
             if (o == 0u) {
                 if (have < used) break;
                 bits <<= used; have -= used;
@@ -1949,9 +1962,7 @@ void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_strid
                 }
                 continue;
             }
-            const uint32_t code = (is_short ? t >> 8 : t >> 4) & 0xFu;
-            const uint32_t len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
-            const uint32_t width = code < 0xCu ? 2u : 4u;
+            const uint32_t len = (packed >> 15) & 15u, width = (packed >> 19) & 7u;
             if (have < used + width) break;
             bits <<= used + width; have -= used + width;
             off = o;
@@ -2117,10 +2128,17 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                 count += kk;
                 bits <<= 9u * kk; have -= 9u * kk;
             } else {
-                const uint32_t t = top >> 11;                    // 1 s ooooooo[oooo] cccc
-                const bool is_short = (t >> 19) & 1u;
-                const uint32_t o = is_short ? (t >> 12) & 0x7Fu : (t >> 8) & 0x7FFu;
-                const uint32_t used = is_short ? 9u : 13u;
+                // 1 s ooooooo[oooo] cccc: fields on the vector unit (see lzs_decompress_blocks_v2_kernel)
+                const uint32_t t = opaque(top) >> 11;
+                const bool is_short_v = (t >> 19) & 1u;
+                const uint32_t o_v = is_short_v ? (t >> 12) & 0x7Fu : (t >> 8) & 0x7FFu;
+                const uint32_t used_v = is_short_v ? 9u : 13u;
+                const uint32_t code_v = (is_short_v ? t >> 8 : t >> 4) & 0xFu;
+                const uint32_t len_v = code_v < 0xCu ? 2u + (code_v >> 2) : code_v - 7u;
+                const uint32_t width_v = code_v < 0xCu ? 2u : 4u;
+                const uint32_t packed = uniform(o_v | (used_v << 11) | (len_v << 15) | (width_v << 19) | ((is_short_v ? 1u : 0u) << 22));
+                const uint32_t o = packed & 0x7FFu, used = (packed >> 11) & 15u;
+                const bool is_short = (packed >> 22) & 1u;
                 if (o == 0u) {
                     if (have < used) break;
                     bits <<= used; have -= used;
@@ -2128,9 +2146,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                     off = 0;                                     // long offset 0: no copy (:280)
                     continue;
                 }
-                const uint32_t code = (is_short ? t >> 8 : t >> 4) & 0xFu;
-                const uint32_t len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
-                const uint32_t width = code < 0xCu ? 2u : 4u;
+                const uint32_t len = (packed >> 15) & 15u, width = (packed >> 19) & 7u;
                 if (have < used + width) break;
                 bits <<= used + width; have -= used + width;
                 off = o;
