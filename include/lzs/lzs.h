@@ -14,9 +14,10 @@
  * A program written against the reference's one-shot calls recompiles against
  * this header and links with -llzs unchanged; the work happens in hand-written
  * HIP kernels on the GPU (there is no CPU codec in this library).  The
- * reference's incremental/streaming entry points (lzs.h:220-232) are outside the
- * scope of this build and are not declared.  Batch and device-pointer entry
- * points, which the reference does not have, are in <lzs/lzs_batch.h>.
+ * reference's incremental entry points (lzs.h:220-232) are declared at the end of
+ * this header; each call is served by the device as well.  Batch and
+ * device-pointer entry points, which the reference does not have, are in
+ * <lzs/lzs_batch.h>.
  */
 #ifndef LZS_MI355X_LZS_H
 #define LZS_MI355X_LZS_H
@@ -73,6 +74,100 @@ size_t lzs_compress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_t 
  * Failure mode and threading as for lzs_compress().
  */
 size_t lzs_decompress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_t * a_pInData, size_t a_inLen);
+
+/* ---------------------------------------------------------------------------
+ * Incremental (resumable) interface: reference lzs.h:90-134, 168-211, 220-232.
+ *
+ * Same parameter blocks (the five public members at the same offsets, the structs
+ * the same sizes: 14432 and 2096 bytes, so objects compiled against either header
+ * are interchangeable), same calling pattern, same status flags.  The private part
+ * holds different things: every call is one or a few kernel launches on the device
+ * plus the copies, and what must survive between calls (history, look-ahead not yet
+ * encoded, bits of an unfinished token, output that did not fit) is kept in the
+ * block itself -- nothing is allocated per stream, a block may be copied or dropped
+ * at any time.  The streams produced and accepted are the reference's, bit for bit.
+ * A call costs ~0.1 ms whatever its size: feed large pieces (MiB) for throughput;
+ * 512-byte pieces, the reference tools' habit, work and run at a few MB/s.
+ * lzs_simple_compress_incremental (a low-RAM variant with the same output) is not
+ * provided.  Without a HIP device: status = LZS_x_STATUS_ERROR, nothing consumed.
+ * ------------------------------------------------------------------------- */
+#define LZS_COMPRESS_HISTORY_SIZE   (LZS_MAX_HISTORY_SIZE + LZS_MAX_LOOK_AHEAD_LEN)
+#define LZS_DECOMPRESS_HISTORY_SIZE LZS_MAX_HISTORY_SIZE
+
+typedef enum
+{
+    LZS_C_STATUS_NONE                   = 0x00,
+    LZS_C_STATUS_INPUT_STARVED          = 0x01, /* all available input has been read */
+    LZS_C_STATUS_INPUT_FINISHED         = 0x02, /* all available input has been read */
+    LZS_C_STATUS_END_MARKER             = 0x04, /* the output contains an end marker */
+    LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE = 0x08, /* output is waiting for space in the output buffer */
+    LZS_C_STATUS_ERROR                  = 0x10  /* no device / a HIP call failed: see lzs_last_error() */
+} LzsCompressStatus_t;
+
+typedef struct
+{
+    /* Set before each call, updated by it (reference lzs.h:107-110). */
+    const uint8_t     * inPtr;      /* in: input data; out: first unread byte */
+    uint8_t           * outPtr;     /* in: output space; out: one past the last byte written */
+    size_t              inLength;   /* in: bytes at inPtr; out: bytes left unread */
+    size_t              outLength;  /* in: space at outPtr; out: space left */
+    uint8_t             status;     /* LzsCompressStatus_t flags of the last call */
+    /* Private.  Sized like the reference's members (lzs.h:123-133). */
+    uint8_t             reserved_[14399];
+} LzsCompressParameters_t;
+
+typedef enum
+{
+    LZS_D_STATUS_NONE                   = 0x00,
+    LZS_D_STATUS_INPUT_STARVED          = 0x01, /* all input read; an unfinished token may be waiting for more */
+    LZS_D_STATUS_INPUT_FINISHED         = 0x02, /* all input read, no bits left over */
+    LZS_D_STATUS_END_MARKER             = 0x04, /* stopped after an end marker */
+    LZS_D_STATUS_NO_OUTPUT_BUFFER_SPACE = 0x08, /* the next byte has no room in the output buffer */
+    LZS_D_STATUS_ERROR                  = 0x10  /* no device / a HIP call failed: see lzs_last_error() */
+} LzsDecompressStatus_t;
+
+typedef struct
+{
+    const uint8_t     * inPtr;
+    uint8_t           * outPtr;
+    size_t              inLength;
+    size_t              outLength;
+    uint8_t             status;     /* LzsDecompressStatus_t flags of the last call */
+    /* Private.  Sized like the reference's members (lzs.h:197-210). */
+    uint8_t             reserved_[2063];
+} LzsDecompressParameters_t;
+
+/* Start a stream (reference lzs-compression.c:479-516; the two differ there in how much
+ * of the tables they clear, here they are the same). */
+void lzs_compress_init_quick(LzsCompressParameters_t * pParams);
+void lzs_compress_init_full(LzsCompressParameters_t * pParams);
+static inline void lzs_compress_init(LzsCompressParameters_t * pParams) { lzs_compress_init_full(pParams); }
+
+/*
+ * Compress the bytes at inPtr into outPtr (reference lzs-compression.c:553-823).  All input is
+ * always taken (up to what the waiting output allows, below); tokens are emitted as soon as
+ * they are decided, which takes 12 bytes of look-ahead (15 inside a long match), so up to 15
+ * bytes are held back until more input arrives or add_end_marker is true.  With add_end_marker
+ * true and inLength 0 everything is flushed and the end marker written (status END_MARKER once
+ * it is out); the history stays, so that a following stream may refer back (RFC 1974).
+ * The concatenated output of any sequence of calls equals lzs_compress() of the concatenated
+ * input.  Output that does not fit outLength (up to 8 KiB of it) waits inside the block and is
+ * delivered first by the next calls (status NO_OUTPUT_BUFFER_SPACE while some is waiting).
+ * Returns the number of bytes written to outPtr.
+ */
+size_t lzs_compress_incremental(LzsCompressParameters_t * pParams, bool add_end_marker);
+
+/* reference lzs-decompression.c:420-428 */
+void lzs_decompress_init(LzsDecompressParameters_t * pParams);
+
+/*
+ * Decompress from inPtr to outPtr until the input is used up (INPUT_STARVED, with
+ * INPUT_FINISHED when no bit of an unfinished token is left), the output is full
+ * (NO_OUTPUT_BUFFER_SPACE; also in the middle of a copy, which resumes at the next call) or an
+ * end marker has been read (END_MARKER: the next call goes on after it, history kept).
+ * reference lzs-decompression.c:459-743.  Returns the number of bytes written to outPtr.
+ */
+size_t lzs_decompress_incremental(LzsDecompressParameters_t * pParams);
 
 #ifdef __cplusplus
 }

@@ -5,11 +5,11 @@ reference's one-shot C-ABI (include/lzs/lzs.h); this package is its ctypes front
 the seeded workload generators used by the benchmark and tests.  No CPU codec, no
 fallback: without the built library or without a GPU, calls raise.
 """
-from .api import (LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
+from .api import (IncrementalCompressor, IncrementalDecompressor, LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
                   compress_stream, compressed_max, decompress, decompress_batch, decompress_blocks, decompress_concat,
                   decompress_stream, decompressed_max, last_error, lib)
 from . import workload
 
-__all__ = ["LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
+__all__ = ["IncrementalCompressor", "IncrementalDecompressor", "LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
            "compress_stream", "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_concat",
            "decompress_stream", "decompressed_max", "last_error", "lib", "workload"]

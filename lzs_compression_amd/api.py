@@ -72,6 +72,11 @@ def lib() -> ctypes.CDLL:
         L.lzs_decompress_stream_device.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _vp, _sz]
         L.lzs_compact_device.restype = ctypes.c_int
         L.lzs_compact_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
+        for name in ("lzs_compress_init_quick", "lzs_compress_init_full", "lzs_decompress_init"):
+            f = getattr(L, name)
+            f.restype, f.argtypes = None, [_vp]
+        L.lzs_compress_incremental.restype, L.lzs_compress_incremental.argtypes = _sz, [_vp, ctypes.c_bool]
+        L.lzs_decompress_incremental.restype, L.lzs_decompress_incremental.argtypes = _sz, [_vp]
         _lib = L
     return _lib
 
@@ -233,3 +238,62 @@ def compact(slots, lengths, stream=None):
                                     slots.stride(0) if nb > 1 else slots.shape[1],
                                     lengths.data_ptr(), nb, _stream_handle(stream)))
     return dense, offsets
+
+
+# ------------------------------------------------------ incremental interface (lzs.h)
+STATUS_INPUT_STARVED, STATUS_INPUT_FINISHED, STATUS_END_MARKER = 0x01, 0x02, 0x04
+STATUS_NO_OUTPUT_BUFFER_SPACE, STATUS_ERROR = 0x08, 0x10
+
+
+class CompressParameters(ctypes.Structure):
+    """LzsCompressParameters_t (reference c/src/liblzs/lzs.h:101-134): same public members,
+    same size."""
+    _fields_ = [("inPtr", _vp), ("outPtr", _vp), ("inLength", _sz), ("outLength", _sz),
+                ("status", ctypes.c_uint8), ("reserved_", ctypes.c_uint8 * 14399)]
+
+
+class DecompressParameters(ctypes.Structure):
+    """LzsDecompressParameters_t (reference c/src/liblzs/lzs.h:180-211)."""
+    _fields_ = [("inPtr", _vp), ("outPtr", _vp), ("inLength", _sz), ("outLength", _sz),
+                ("status", ctypes.c_uint8), ("reserved_", ctypes.c_uint8 * 2063)]
+
+
+class _Incremental:
+    """One parameter block driven the way the reference's tools and tests drive it: set
+    inPtr/inLength/outPtr/outLength, call, read back what moved."""
+
+    def _call(self, fn, data: bytes, out_space: int, *extra):
+        src = ctypes.create_string_buffer(bytes(data), max(len(data), 1))
+        dst = ctypes.create_string_buffer(max(out_space, 1))
+        p = self.params
+        p.inPtr, p.inLength = ctypes.addressof(src), len(data)
+        p.outPtr, p.outLength = ctypes.addressof(dst), out_space
+        n = fn(ctypes.addressof(p), *extra)
+        if p.status & STATUS_ERROR:
+            raise LzsError(LZS_E_HIP, last_error())
+        assert n == out_space - p.outLength and p.outPtr == ctypes.addressof(dst) + n
+        assert p.inPtr == ctypes.addressof(src) + len(data) - p.inLength
+        return dst.raw[:n], len(data) - p.inLength, int(p.status)
+
+
+class IncrementalCompressor(_Incremental):
+    """lzs_compress_init() + lzs_compress_incremental() (reference lzs-compression.c:479-823)."""
+
+    def __init__(self):
+        self.params = CompressParameters()
+        lib().lzs_compress_init_full(ctypes.addressof(self.params))
+
+    def step(self, data: bytes, out_space: int, add_end_marker: bool = False):
+        """One call: returns (output bytes, input bytes consumed, status flags)."""
+        return self._call(lib().lzs_compress_incremental, data, out_space, add_end_marker)
+
+
+class IncrementalDecompressor(_Incremental):
+    """lzs_decompress_init() + lzs_decompress_incremental() (reference lzs-decompression.c:420-743)."""
+
+    def __init__(self):
+        self.params = DecompressParameters()
+        lib().lzs_decompress_init(ctypes.addressof(self.params))
+
+    def step(self, data: bytes, out_space: int):
+        return self._call(lib().lzs_decompress_incremental, data, out_space)

@@ -63,6 +63,24 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
                                  const uint32_t *d_out_start, void *stream);
 int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
                                   uint32_t *d_left, void *stream);
+/* The incremental entry points (lzs_incremental.c).  Status bits as in the reference's
+ * LzsCompressStatus_t / LzsDecompressStatus_t (lzs.h:90-98, 168-176). */
+#define LZS_INC_INPUT_STARVED   0x01u
+#define LZS_INC_INPUT_FINISHED  0x02u
+#define LZS_INC_END_MARKER      0x04u
+#define LZS_INC_NO_OUTPUT_SPACE 0x08u
+#define LZS_INC_ERROR           0x10u
+/* What the incremental decoder carries from call to call (lzs_decode_resume_kernel reads and
+ * rewrites it in device memory; the host keeps it in the caller's LzsDecompressParameters_t). */
+typedef struct {
+    uint32_t bitq, qlen;            /* bits of an unfinished token, left-aligned; how many */
+    uint32_t off, rem, extended;    /* copy in progress: offset, bytes left, a nibble follows */
+    uint32_t hist_len;              /* bytes of history in hist[] (oldest first), <= 2047 */
+    uint32_t in_used, out_made, status, reserved;   /* results of the call */
+    uint8_t  hist[2048];
+} lzs_dec_resume_t;
+int lzs_hip_launch_decode_resume(lzs_dec_resume_t *d_state, const void *d_in, uint32_t n,
+                                 void *d_out, uint32_t cap, void *stream);
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks,
                            void *stream);

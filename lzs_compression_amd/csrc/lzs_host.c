@@ -609,3 +609,118 @@ size_t lzs_decompress_concat(uint8_t *out, size_t out_cap, const uint8_t *in, si
 {
     return one_shot("lzs_decompress_concat", lzs_hip_launch_decompress_concat, out, out_cap, in, in_len);
 }
+
+/* ------------------------------------------------------- incremental interface: decoding */
+/* reference lzs-decompression.c:420-743.  What the reference keeps in its private members is
+ * kept here, in the same bytes of the caller's block, in this layout; every call ships it to
+ * the device with the input and back (lzs_decode_resume_kernel). */
+typedef struct __attribute__((packed)) {
+    uint32_t bitq;                  /* bits of an unfinished token, left-aligned */
+    uint16_t off;                   /* copy in progress: offset */
+    uint16_t hist_len;              /* bytes in hist[], oldest first */
+    uint8_t  qlen, rem, extended;   /* bits in bitq; copy bytes left; a length nibble follows */
+    uint8_t  hist[LZS_MAX_HISTORY_SIZE];
+} dec_priv_t;
+#define DEC_PRIV_AT 36u
+_Static_assert(sizeof(LzsDecompressParameters_t) == 2096, "size of the reference's LzsDecompressParameters_t");
+_Static_assert(sizeof(LzsCompressParameters_t) == 14432, "size of the reference's LzsCompressParameters_t");
+_Static_assert(DEC_PRIV_AT + sizeof(dec_priv_t) <= sizeof(LzsDecompressParameters_t), "private state fits");
+
+void lzs_decompress_init(LzsDecompressParameters_t *p)
+{
+    if (!p) return;
+    p->status = LZS_D_STATUS_NONE;
+    memset(p->reserved_, 0, sizeof(p->reserved_));
+}
+
+size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
+{
+    const char *who = "lzs_decompress_incremental";
+    if (!p) return 0;
+    dec_priv_t *pv = (dec_priv_t *)((uint8_t *)p + DEC_PRIV_AT);
+    size_t made = 0;
+    int e = 0;
+    p->status = LZS_D_STATUS_NONE;
+    tls_error[0] = 0;
+    /* nothing to read and nothing queued: the answer needs no device (:475-478) */
+    if (p->inLength == 0 && pv->qlen == 0 && pv->rem == 0) {
+        p->status = LZS_D_STATUS_INPUT_FINISHED | LZS_D_STATUS_INPUT_STARVED;
+        return 0;
+    }
+    if ((p->inLength && !p->inPtr) || (p->outLength && !p->outPtr)) {
+        fail(LZS_E_ARG, "%s: NULL buffer", who);
+        p->status = LZS_D_STATUS_ERROR;
+        return 0;
+    }
+    if (require_device() != LZS_OK) goto failed;
+    staging_t *st = staging_get();
+    if (!st) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+#define HIP_TRY(call, what) do { e = (call); if (e) { hip_fail(e, what); goto failed; } } while (0)
+    if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
+    void *stream = st->stream;
+    lzs_dec_resume_t h;
+    memset(&h, 0, sizeof(h));
+    for (;;) {
+        /* one launch takes at most 16 MiB of input; its output is bounded by 30x that
+         * (a length nibble stands for 15 bytes) */
+        const size_t take = p->inLength < ((size_t)16 << 20) ? p->inLength : ((size_t)16 << 20);
+        const size_t most = 30u * (take + 4u) + 64u;
+        const size_t cap = p->outLength < most ? p->outLength : most;
+        void *d_in = NULL, *d_out = NULL, *d_state = NULL;
+        e = staging_reserve(st, BUF_IN, take + 64, &d_in);
+        if (!e) e = staging_reserve(st, BUF_OUT, cap + 64, &d_out);
+        if (!e) e = staging_reserve(st, BUF_AUX, sizeof(h), &d_state);
+        if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+        h.bitq = pv->bitq; h.qlen = pv->qlen; h.off = pv->off; h.rem = pv->rem;
+        h.extended = pv->extended; h.hist_len = pv->hist_len;
+        memcpy(h.hist, pv->hist, pv->hist_len);
+        HIP_TRY(lzs_hip_h2d(d_state, &h, sizeof(h), stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d(d_in, p->inPtr, take, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_launch_decode_resume((lzs_dec_resume_t *)d_state, d_in, (uint32_t)take, d_out, (uint32_t)cap, stream), who);
+        HIP_TRY(lzs_hip_d2h(&h, d_state, sizeof(h), stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        if (h.in_used > take || h.out_made > cap || h.hist_len > LZS_MAX_HISTORY_SIZE) {
+            fail(LZS_E_HIP, "%s: inconsistent state from the device", who);
+            goto failed;
+        }
+        HIP_TRY(lzs_hip_d2h(p->outPtr, d_out, h.out_made, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        pv->bitq = h.bitq; pv->qlen = (uint8_t)h.qlen; pv->off = (uint16_t)h.off; pv->rem = (uint8_t)h.rem;
+        pv->extended = (uint8_t)h.extended; pv->hist_len = (uint16_t)h.hist_len;
+        memcpy(pv->hist, h.hist, h.hist_len);
+        p->inPtr += h.in_used;   p->inLength -= h.in_used;
+        p->outPtr += h.out_made; p->outLength -= h.out_made;
+        made += h.out_made;
+        /* stopped only because of this loop's own limits: go on */
+        if ((h.status & LZS_INC_INPUT_STARVED) && p->inLength) continue;
+        if ((h.status & LZS_INC_NO_OUTPUT_SPACE) && p->outLength && cap == most) continue;
+        p->status = (uint8_t)h.status;
+        break;
+    }
+#undef HIP_TRY
+    staging_trim(st);
+    return made;
+
+failed:
+    p->status = LZS_D_STATUS_ERROR;
+    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+    { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
+    return made;
+}
+
+/* ---------------------------------------------------- incremental interface: compression */
+void lzs_compress_init_full(LzsCompressParameters_t *p)
+{
+    if (!p) return;
+    p->status = LZS_C_STATUS_NONE;
+    memset(p->reserved_, 0, sizeof(p->reserved_));
+}
+
+void lzs_compress_init_quick(LzsCompressParameters_t *p) { lzs_compress_init_full(p); }
+
+size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
+{
+    (void)add_end_marker;
+    if (p) p->status = LZS_C_STATUS_ERROR;
+    return 0;
+}

@@ -2327,6 +2327,148 @@ void lzs_gather_slots_kernel(uint8_t *__restrict__ dense, const uint64_t *__rest
     if (threadIdx.x < n - done) d[done + threadIdx.x] = s[done + threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------
+// lzs_decompress_incremental(): one call's worth of decoding, resumable.
+// reference lzs-decompression.c:459-743 (a 9-state machine over a 32-bit queue; here the same
+// stop rules at token granularity).  One wavefront.  `st` carries what the reference keeps in
+// LzsDecompressParameters_t between calls: the bits of an unfinished token, the copy in progress
+// (offset, bytes left, extended), and the last <= 2047 bytes of output as history.  The call
+// stops when the input runs out (INPUT_STARVED, with INPUT_FINISHED if no bit is left), when the
+// next byte has no room in `out` (NO_OUTPUT_BUFFER_SPACE, also in the middle of a copy), or after
+// an end marker (END_MARKER: the pad bits up to the byte boundary are dropped, :564-576, and
+// history is kept for what follows).  Whole unread input bytes are handed back (in_used).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void lzs_decode_resume_kernel(lzs_dec_resume_t *__restrict__ st, const uint8_t *__restrict__ in, uint32_t n,
+                              uint8_t *__restrict__ out, uint32_t cap)
+{
+    __shared__ uint32_t ring[kRingWords];
+    uint8_t *ring8 = reinterpret_cast<uint8_t *>(ring);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base = uniform(st->hist_len);                  // ring position of out[0]
+    for (uint32_t i = lane; i < base; i += 64) ring8[i] = st->hist[i];
+    __builtin_amdgcn_wave_barrier();
+
+    uint64_t bits = (uint64_t)uniform(st->bitq) << 32;            // left-aligned
+    uint32_t have = uniform(st->qlen);
+    const uint32_t carried = have;                                // bits that are not from `in`
+    uint32_t off = uniform(st->off), rem = uniform(st->rem);
+    bool extended = uniform(st->extended) != 0;
+    uint32_t ipos = 0;                                            // next input byte to feed (multiple of 4)
+    uint32_t count = base, flushed = base;
+    const uint32_t limit = base + cap;
+    uint32_t status = 0;
+    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in);   // staged 4-aligned, padded by the host
+
+    for (;;) {
+        while (have <= 32 && ipos < n) {
+            uint32_t w = uniform(__builtin_bswap32(in32[ipos >> 2]));
+            const uint32_t nb = n - ipos < 4 ? n - ipos : 4;
+            if (nb < 4) w &= ~0u << (8 * (4 - nb));
+            bits |= (uint64_t)w << (32 - have);
+            have += 8 * nb;
+            ipos += 4;
+        }
+        if (rem == 0) {
+            if (have == 0) { status |= LZS_INC_INPUT_FINISHED | LZS_INC_INPUT_STARVED; break; }   // :475-478
+            bool starved = false;
+            if (extended) {                                        // :706-723
+                if (have < 4) starved = true;
+                else {
+                    const uint32_t e = (uint32_t)(bits >> 60);
+                    bits <<= 4; have -= 4;
+                    rem = e;
+                    if (e != kNibbleMax) extended = false;
+                }
+            } else if ((bits >> 63) == 0) {                        // literals :516-541, up to 7 at once
+                if (have < 9) starved = true;
+                else if (count >= limit) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
+                else {
+                    const uint64_t types = bits & 0x8040201008040200ull;
+                    uint32_t k = (types ? (uint32_t)__builtin_clzll(types) : 64u) / 9u;
+                    k = k < have / 9u ? k : have / 9u;
+                    k = k < limit - count ? k : limit - count;
+                    if (lane < k) ring8[(count + lane) & kRingMask] = (uint8_t)(bits >> (55u - 9u * lane));
+                    count += k;
+                    bits <<= 9u * k; have -= 9u * k;
+                }
+            } else {                                               // offset, then length or end marker
+                const bool is_short = ((bits >> 62) & 1u) != 0;
+                const uint32_t used = is_short ? 9u : 13u;
+                if (have < used) starved = true;
+                else {
+                    const uint32_t o = is_short ? (uint32_t)(bits >> 55) & 0x7Fu : (uint32_t)(bits >> 51) & 0x7FFu;
+                    if (o == 0) {
+                        bits <<= used; have -= used;
+                        if (is_short) {                            // end marker :564-576
+                            const uint32_t pad = have & 7u;
+                            bits <<= pad; have -= pad;
+                            status |= LZS_INC_END_MARKER;
+                            break;
+                        }
+                        off = 0;                                   // long offset 0: no copy (one-shot rule, :280)
+                    } else {
+                        const uint32_t code = (uint32_t)((bits << used) >> 60);
+                        const uint32_t width = code < 0xCu ? 2u : 4u;
+                        if (have < used + width) starved = true;
+                        else {
+                            const uint32_t len = code < 0xCu ? 2u + (code >> 2) : 5u + (code - 0xCu);
+                            bits <<= used + width; have -= used + width;
+                            off = o;
+                            rem = len;
+                            extended = len == kTokenMax;
+                        }
+                    }
+                }
+            }
+            if (starved) { status |= LZS_INC_INPUT_STARVED; break; }     // the token's bits stay queued
+        }
+        if (rem) {                                                 // :640-704
+            const uint32_t room = limit - count;
+            if (room == 0) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
+            const uint32_t m = rem < room ? rem : room;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t v = 0;
+            if (lane < m) {
+                const uint32_t k = off > 15u ? lane : lane % off;
+                const uint32_t from = count + k;
+                v = from >= off ? ring8[(from - off) & kRingMask] : 0u;   // before the history's start -> 0 (:676-683)
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < m) ring8[(count + lane) & kRingMask] = (uint8_t)v;
+            count += m;
+            rem -= m;
+        }
+        if (count - flushed >= kTile) {
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = flushed + lane; i < count; i += 64) out[i - base] = ring8[i & kRingMask];
+            flushed = count;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = flushed + lane; i < count; i += 64) out[i - base] = ring8[i & kRingMask];
+
+    // whole bytes of this call's input that were not needed go back to the caller
+    const uint32_t fed = ipos < n ? ipos : n;
+    const uint32_t consumed = carried + 8u * fed - have;          // bits used up in this call
+    const uint32_t fed_left = consumed >= carried ? have : 8u * fed;
+    // (a starved call keeps the unfinished token's bits, < 17, and takes all the input, as the
+    // reference does: its callers read more only when inLength is 0)
+    const uint32_t back = (status & LZS_INC_INPUT_STARVED) ? 0u : fed_left >> 3;
+    have -= 8u * back;
+    const uint32_t hist_len = count < kWindow ? count : kWindow;
+    for (uint32_t i = lane; i < hist_len; i += 64) st->hist[i] = ring8[(count - hist_len + i) & kRingMask];
+    if (lane == 0) {
+        st->bitq = (uint32_t)(bits >> 32) & (have ? ~0u << (32u - have) : 0u);
+        st->qlen = have;
+        st->off = off; st->rem = rem; st->extended = extended ? 1u : 0u;
+        st->hist_len = hist_len;
+        st->in_used = fed - back;
+        st->out_made = count - base;
+        st->status = status;
+    }
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -2497,6 +2639,15 @@ int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slo
     hipLaunchKernelGGL(lzs_gather_slots_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
                        (uint8_t *)d_dense, d_offsets, (const uint8_t *)d_slots, slot_stride, d_len,
                        nblocks);
+    return (int)hipGetLastError();
+}
+
+
+int lzs_hip_launch_decode_resume(lzs_dec_resume_t *d_state, const void *d_in, uint32_t n,
+                                 void *d_out, uint32_t cap, void *stream)
+{
+    hipLaunchKernelGGL(lzs_decode_resume_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       d_state, (const uint8_t *)d_in, n, (uint8_t *)d_out, cap);
     return (int)hipGetLastError();
 }
 
