@@ -18,6 +18,7 @@ def _declared_functions():
     for hdr in ("lzs/lzs.h", "lzs/lzs_batch.h"):
         text = open(os.path.join(INC, hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"static inline[^{]*\{[^}]*\}", "", text)       # header-only, as in the reference (lzs.h:239)
         names += re.findall(r"\b(lzs_[a-z_]+)\s*\(", text)
     return sorted(set(names))
 
