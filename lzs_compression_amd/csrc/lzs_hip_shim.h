@@ -43,14 +43,22 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
  * count; only segments with d_dirty[k] != 0 run (NULL: all).  lzs_stitch_segments_kernel then ORs
  * the slots into the zeroed, 4-aligned d_out at d_bit_at[k] and appends the end marker.  A segment
  * whose bits did not fit its slot (d_nbits[k] > 8 * slot_stride: a very long match) is run once more
- * with d_out / d_bit_at set and ORs its bits in directly. */
+ * with d_out / d_bit_at set and ORs its bits in directly.
+ * A piece of a stream that will go on (the incremental interface): no token starts at or after
+ * `lim` (= n for a whole stream), d_open[2k..] receives {offset, start} of segment k's last token
+ * if that is a match reaching n (it may still grow), and no end marker is written.  A piece that
+ * begins inside such a match has lzs_extend_resume_kernel write its length nibbles first
+ * (d_result: next position, still open, bits written low/high). */
 int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
-                                     void *d_out, const uint64_t *d_bit_at, void *stream);
+                                     void *d_out, const uint64_t *d_bit_at, uint32_t lim, uint32_t *d_open,
+                                     void *stream);
 int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot_stride,
                                    const uint64_t *d_bit_at, const uint64_t *d_nbits, uint32_t nseg,
-                                   void *stream);
+                                   int end_marker, void *stream);
+int lzs_hip_launch_extend_resume(void *d_out, uint32_t bit0, const void *d_in, uint32_t n, uint32_t c0,
+                                 uint32_t off, int last, uint32_t *d_result, void *stream);
 /* One long stream decompressed by many wavefronts (lzs_scan_stream_kernel, lzs_decode_stream_kernel,
  * lzs_resolve_stream_kernel; state words and the scheme are described at the kernels). */
 #define LZS_SEG_STOP (1u << 30)

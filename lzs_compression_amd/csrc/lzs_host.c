@@ -319,16 +319,35 @@ static double now_ms(void)
 #define STREAM_MIN   (2u * STREAM_SEG)          /* shorter inputs stay with one workgroup */
 
 /* in/out on the host (dev == 0: staged through this thread's device buffers) or on the device */
-static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status)
+/* A piece of a stream for lzs_compress_incremental(): the data is `prefix` (history and the
+ * bytes the call before could not encode yet) followed by `in`; encoding starts at c0, inside a
+ * long match if ext_off is set, at bit bit0 of the first output byte (whose earlier bits are in
+ * `first`).  Unless `last`, it stops where the tokens are no longer decided by the data so far. */
+typedef struct {
+    const uint8_t *prefix;
+    uint32_t prefix_len;
+    uint32_t c0, ext_off, bit0;
+    uint8_t  first;
+    int      last;
+    /* results */
+    uint32_t c_exit;        /* everything before it is encoded */
+    uint32_t ext_exit;      /* != 0: still inside a long match at this offset */
+    uint64_t nbits;         /* bits in the output (bit0 included, end marker not) */
+} piece_t;
+
+static size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status,
+                                    piece_t *pc)
 {
-    const char *who = dev ? "lzs_compress_stream_device" : "lzs_compress";
-    const uint32_t nseg = (uint32_t)((n + STREAM_SEG - 1) / STREAM_SEG);
-    const size_t worst = LZS_COMPRESSED_MAX(n);
+    const char *who = pc ? "lzs_compress_incremental" : dev ? "lzs_compress_stream_device" : "lzs_compress";
+    const uint32_t nseg = n ? (uint32_t)((n + STREAM_SEG - 1) / STREAM_SEG) : 1u;
+    const size_t worst = LZS_COMPRESSED_MAX(n - (pc ? pc->c0 : 0)) + 8;
+    const int end_marker = !pc || pc->last;
+    const uint32_t lim = end_marker ? (uint32_t)n : (n > LZS_MAX_LOOK_AHEAD_LEN ? (uint32_t)n - LZS_MAX_LOOK_AHEAD_LEN : 0u);
     size_t result = 0;
     int e = 0, rc = LZS_OK;
     void *d_in = NULL, *d_out = NULL, *d_aux = NULL, *d_slots = NULL;
     const size_t slot_stride = (LZS_COMPRESSED_MAX((size_t)STREAM_SEG) + 15u) & ~(size_t)15u;
-    uint32_t *entry = NULL, *exitp = NULL;
+    uint32_t *entry = NULL, *exitp = NULL, *openi = NULL;
     uint64_t *nbits = NULL, *bitat = NULL;
     uint8_t *dirty = NULL;
     tls_error[0] = 0;
@@ -340,13 +359,14 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     nbits = (uint64_t *)malloc(sizeof(uint64_t) * nseg);
     bitat = (uint64_t *)malloc(sizeof(uint64_t) * nseg);
     dirty = (uint8_t *)malloc(nseg);
-    if (!entry || !exitp || !nbits || !bitat || !dirty) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+    openi = (uint32_t *)malloc(sizeof(uint32_t) * 2 * nseg);
+    if (!entry || !exitp || !nbits || !bitat || !dirty || !openi) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
 
 #define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto failed; } } while (0)
     if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
     void *stream = st->stream;
-    /* device arrays in one allocation: bit_at, nbits (8 B each), entry, exit (4 B each), dirty */
-    const size_t aux_bytes = (size_t)nseg * (8 + 8 + 4 + 4 + 1) + 64;
+    /* device arrays in one allocation: bit_at, nbits (8 B each), entry, exit, open info (4 + 4 + 8 B), dirty */
+    const size_t aux_bytes = (size_t)nseg * (8 + 8 + 4 + 4 + 8 + 1) + 64;
     if (dev) { d_in = (void *)in; d_out = out; }
     else {
         e = staging_reserve(st, BUF_IN, n + 64, &d_in);
@@ -359,19 +379,45 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     uint64_t *d_nbits = d_bitat + nseg;
     uint32_t *d_entry = (uint32_t *)(d_nbits + nseg);
     uint32_t *d_exit = d_entry + nseg;
-    uint8_t *d_dirty = (uint8_t *)(d_exit + nseg);
+    uint32_t *d_open = d_exit + nseg;
+    uint8_t *d_dirty = (uint8_t *)(d_open + 2 * (size_t)nseg);
 
     const int debug = getenv("LZS_STREAM_DEBUG") != NULL;      /* stage times on stderr */
     double t0 = debug ? now_ms() : 0, t1;
-    if (!dev) HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
+    if (!dev) {
+        const size_t pre = pc ? pc->prefix_len : 0;
+        if (pre) HIP_TRY(lzs_hip_h2d(d_in, pc->prefix, pre, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + pre, in, n - pre, stream), "hipMemcpy H2D");
+    }
     HIP_TRY(lzs_hip_memset(d_out, 0, worst + 1024, stream), "hipMemset");
     if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: %zu B, %u segments; H2D + memset %.2f ms\n", n, nseg, t1 - t0); t0 = t1; }
-    for (uint32_t k = 0; k < nseg; k++) { entry[k] = k * STREAM_SEG; dirty[k] = 1; }
-    for (uint32_t round = 0, ndirty = nseg; ndirty; round++) {
+    uint32_t c_first = 0, ext_now = 0;
+    uint64_t total = 0;
+    if (pc) {
+        c_first = pc->c0;
+        total = pc->bit0;
+        if (pc->bit0) HIP_TRY(lzs_hip_h2d(d_out, &pc->first, 1, stream), "hipMemcpy H2D");
+        if (pc->ext_off) {
+            /* the piece begins inside a long match: its length nibbles first (d_exit as scratch) */
+            uint32_t res[4];
+            HIP_TRY(lzs_hip_launch_extend_resume(d_out, pc->bit0, d_in, (uint32_t)n, pc->c0, pc->ext_off, pc->last, d_exit, stream), who);
+            HIP_TRY(lzs_hip_d2h(res, d_exit, sizeof(res), stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+            c_first = res[0];
+            ext_now = res[1] ? pc->ext_off : 0;
+            total += ((uint64_t)res[3] << 32) | res[2];
+        }
+    }
+    for (uint32_t k = 0; k < nseg; k++) {
+        entry[k] = k * STREAM_SEG > c_first ? k * STREAM_SEG : c_first;
+        dirty[k] = 1; exitp[k] = entry[k]; nbits[k] = 0; openi[2 * k] = openi[2 * k + 1] = 0;
+    }
+    /* (a match still open after the nibbles covers all the data there is: no tokens in this piece) */
+    for (uint32_t round = 0, ndirty = ext_now ? 0 : nseg; ndirty; round++) {
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_compress_segments(d_slots, slot_stride, d_in, (uint32_t)n, STREAM_SEG, nseg,
-                                                 d_entry, d_dirty, d_exit, d_nbits, NULL, NULL, stream), who);
+                                                 d_entry, d_dirty, d_exit, d_nbits, NULL, NULL, lim, pc ? d_open : NULL, stream), who);
         HIP_TRY(lzs_hip_d2h(exitp, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         /* a segment is entered where the one before stopped (its own start for segment 0) */
@@ -384,12 +430,38 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
         }
         if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream: round %u compressed %u segments in %.2f ms; %u to redo\n", round, was, t1 - t0, ndirty); t0 = t1; }
     }
-    HIP_TRY(lzs_hip_d2h(nbits, d_nbits, sizeof(uint64_t) * nseg, stream), "hipMemcpy D2H");
-    HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
-    uint64_t total = 0;
+    if (!ext_now) {
+        HIP_TRY(lzs_hip_d2h(nbits, d_nbits, sizeof(uint64_t) * nseg, stream), "hipMemcpy D2H");
+        if (pc) HIP_TRY(lzs_hip_d2h(openi, d_open, sizeof(uint32_t) * 2 * nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    }
+    if (pc) {
+        pc->c_exit = ext_now ? c_first : exitp[nseg - 1];
+        pc->ext_exit = ext_now;
+        if (!pc->last && !ext_now && pc->c_exit >= n && n > c_first) {
+            /* The last token is a match that reaches the end of the data so far: it may go on in
+             * the next piece.  Its full groups of 15 stand; the closing nibble is taken back and
+             * the bytes it covered wait for more data (state COMPRESS_EXTENDED, :750-758). */
+            uint32_t k = nseg;
+            while (k > 0 && openi[2 * (k - 1)] == 0) k--;
+            if (k == 0 || nbits[k - 1] < 4) {
+                rc = fail(LZS_E_HIP, "%s: inconsistent state from the device (piece of %zu bytes from %u ends at %u, no open match reported)",
+                          who, n, c_first, pc->c_exit);
+                goto failed;
+            }
+            const uint32_t off = openi[2 * (k - 1)], start = openi[2 * (k - 1) + 1];
+            const uint32_t rest = ((uint32_t)n - start - 8u) % 15u;
+            nbits[k - 1] -= 4;
+            HIP_TRY(lzs_hip_h2d(d_nbits, nbits, sizeof(uint64_t) * nseg, stream), "hipMemcpy H2D");
+            pc->c_exit = (uint32_t)n - rest;
+            pc->ext_exit = off;
+        }
+    }
     for (uint32_t k = 0; k < nseg; k++) { bitat[k] = total; total += nbits[k]; }
+    if (pc) pc->nbits = total;
     HIP_TRY(lzs_hip_h2d(d_bitat, bitat, sizeof(uint64_t) * nseg, stream), "hipMemcpy H2D");
-    HIP_TRY(lzs_hip_launch_stitch_segments(d_out, d_slots, slot_stride, d_bitat, d_nbits, nseg, stream), who);
+    if (!ext_now)
+        HIP_TRY(lzs_hip_launch_stitch_segments(d_out, d_slots, slot_stride, d_bitat, d_nbits, nseg, end_marker, stream), who);
     /* segments whose bits did not fit their slot (a match running on for more than ~120 KB past
      * the segment): once more, ORed straight into place */
     uint32_t nbig = 0;
@@ -397,10 +469,11 @@ static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_
     if (nbig) {
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_compress_segments(d_slots, slot_stride, d_in, (uint32_t)n, STREAM_SEG, nseg,
-                                                 d_entry, d_dirty, d_exit, d_nbits, d_out, d_bitat, stream), who);
+                                                 d_entry, d_dirty, d_exit, d_nbits, d_out, d_bitat, lim, NULL, stream), who);
     }
     if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: stitch %.2f ms\n", t1 - t0); t0 = t1; }
-    result = (size_t)((total + 9 + 7) / 8);                    /* end marker, padded to a byte */
+    result = end_marker ? (size_t)((total + 9 + 7) / 8)        /* end marker, padded to a byte */
+                        : (size_t)((total + 7) / 8);            /* a piece: the last byte may be partial */
     if (result > cap) result = cap;                            /* cut at the capacity, prefix unchanged */
     if (!dev) HIP_TRY(lzs_hip_d2h(out, d_out, result, stream), "hipMemcpy D2H");
     HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -413,10 +486,15 @@ failed:
     if (!dev) fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
 done:
-    free(entry); free(exitp); free(nbits); free(bitat); free(dirty);
+    free(entry); free(exitp); free(nbits); free(bitat); free(dirty); free(openi);
     { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
     if (status) *status = rc;
     return result;
+}
+
+static size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status)
+{
+    return stream_compress_piece(out, cap, in, n, dev, status, NULL);
 }
 
 int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len, const void *d_in, size_t in_len)
@@ -709,6 +787,29 @@ failed:
 }
 
 /* ---------------------------------------------------- incremental interface: compression */
+/* reference lzs-compression.c:479-823.  Between calls the caller's block holds, in place of the
+ * reference's ring and hash tables: the last INC_HIST bytes already encoded (what the next
+ * piece's chains are built from: lzs_compress_segments_kernel warms up over 2176 + 64 bytes
+ * before its first token), the <= 15 bytes after them that wait for more look-ahead, the offset
+ * of a long match still running, the bits of the last, partial output byte, and output that
+ * found no room.  Every call encodes what the data so far decides, as one piece of the stream
+ * on the device (stream_compress_piece). */
+#define INC_HIST      2304u
+#define INC_CARRY_MAX 16u
+#define INC_PEND_MAX  8192u
+typedef struct __attribute__((packed)) {
+    uint32_t data_len;              /* bytes in data[]: history, then carry_len bytes not yet encoded */
+    uint32_t carry_len;
+    uint32_t pend_pos, pend_len;    /* output waiting in pend[pend_pos .. pend_len) */
+    uint16_t ext_off;               /* != 0: inside a long match at this offset */
+    uint8_t  bit_len, bit_val;      /* bits of the partial last output byte, left-aligned */
+    uint8_t  marker_waiting;        /* the end marker is among the waiting output */
+    uint8_t  data[INC_HIST + INC_CARRY_MAX];
+    uint8_t  pend[INC_PEND_MAX];
+} enc_priv_t;
+#define ENC_PRIV_AT 40u
+_Static_assert(ENC_PRIV_AT + sizeof(enc_priv_t) <= sizeof(LzsCompressParameters_t), "private state fits");
+
 void lzs_compress_init_full(LzsCompressParameters_t *p)
 {
     if (!p) return;
@@ -718,9 +819,116 @@ void lzs_compress_init_full(LzsCompressParameters_t *p)
 
 void lzs_compress_init_quick(LzsCompressParameters_t *p) { lzs_compress_init_full(p); }
 
+/* hand `len` bytes to the caller's buffer, what does not fit to pend[] (room was reserved) */
+static size_t inc_deliver(LzsCompressParameters_t *p, enc_priv_t *pv, const uint8_t *src, size_t len)
+{
+    const size_t now = len < p->outLength ? len : p->outLength;
+    memcpy(p->outPtr, src, now);
+    p->outPtr += now; p->outLength -= now;
+    memcpy(pv->pend, src + now, len - now);
+    pv->pend_pos = 0; pv->pend_len = (uint32_t)(len - now);
+    return now;
+}
+
 size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
 {
-    (void)add_end_marker;
-    if (p) p->status = LZS_C_STATUS_ERROR;
-    return 0;
+    const char *who = "lzs_compress_incremental";
+    if (!p) return 0;
+    enc_priv_t *pv = (enc_priv_t *)((uint8_t *)p + ENC_PRIV_AT);
+    size_t made = 0;
+    uint8_t *tmp = NULL;
+    p->status = LZS_C_STATUS_NONE;
+    tls_error[0] = 0;
+    if ((p->inLength && !p->inPtr) || (p->outLength && !p->outPtr) ||
+        pv->data_len > sizeof(pv->data) || pv->carry_len > pv->data_len || pv->pend_len > INC_PEND_MAX || pv->pend_pos > pv->pend_len) {
+        fail(LZS_E_ARG, "%s: NULL buffer or a parameter block that was not initialised", who);
+        p->status = LZS_C_STATUS_ERROR;
+        return 0;
+    }
+    /* output still waiting from the call before goes first (:574-588) */
+    if (pv->pend_pos < pv->pend_len) {
+        const size_t have = pv->pend_len - pv->pend_pos;
+        const size_t now = have < p->outLength ? have : p->outLength;
+        memcpy(p->outPtr, pv->pend + pv->pend_pos, now);
+        p->outPtr += now; p->outLength -= now; pv->pend_pos += (uint32_t)now; made += now;
+        if (pv->pend_pos < pv->pend_len) {
+            p->status = LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
+            return made;
+        }
+        pv->pend_pos = pv->pend_len = 0;
+        if (pv->marker_waiting) {
+            pv->marker_waiting = 0;
+            p->status = LZS_C_STATUS_END_MARKER | (p->inLength ? 0 : LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED);
+            return made;
+        }
+    }
+    for (;;) {
+        /* Take as much input as the room for its output allows: 9 bits a byte at worst, into the
+         * caller's buffer and then into pend[]; one piece is at most 1 GiB. */
+        const size_t room = p->outLength + INC_PEND_MAX;
+        const size_t fits = (8u * room - 64u) / 9u - pv->carry_len;
+        size_t take = p->inLength < fits ? p->inLength : fits;
+        if (take > ((size_t)1 << 30)) take = (size_t)1 << 30;
+        const int last = add_end_marker && take == p->inLength;
+        const size_t n = (size_t)pv->data_len + take;
+        const uint32_t c0 = pv->data_len - pv->carry_len;
+        if (!last && n - c0 <= LZS_MAX_LOOK_AHEAD_LEN) {
+            /* too little to decide the next token (:641-647): it waits in the block */
+            memcpy(pv->data + pv->data_len, p->inPtr, take);
+            pv->data_len += (uint32_t)take; pv->carry_len += (uint32_t)take;
+            p->inPtr += take; p->inLength -= take;
+            break;
+        }
+        piece_t pc;
+        memset(&pc, 0, sizeof(pc));
+        pc.prefix = pv->data; pc.prefix_len = pv->data_len;
+        pc.c0 = c0; pc.ext_off = pv->ext_off; pc.bit0 = pv->bit_len; pc.first = pv->bit_val; pc.last = last;
+        const size_t cap = LZS_COMPRESSED_MAX(n - c0) + 16;
+        tmp = (uint8_t *)malloc(cap);
+        if (!tmp) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+        int rc = LZS_OK;
+        const size_t got = stream_compress_piece(tmp, cap, p->inPtr, n, 0, &rc, &pc);
+        if (rc != LZS_OK) goto failed_quiet;
+        const size_t whole = last ? got : (size_t)(pc.nbits / 8);
+        if (whole > got || whole > room || pc.c_exit > n || pc.c_exit < c0 || (last ? pc.c_exit != n : n - pc.c_exit > INC_CARRY_MAX - 1u)) {
+            fail(LZS_E_HIP, "%s: inconsistent state from the device (piece of %zu bytes from %u: %zu bytes out, %llu bits, ends at %u, room %zu)",
+                 who, n, c0, got, (unsigned long long)pc.nbits, pc.c_exit, room);
+            goto failed;
+        }
+        made += inc_deliver(p, pv, tmp, whole);
+        pv->bit_len = last ? 0 : (uint8_t)(pc.nbits & 7u);
+        pv->bit_val = pv->bit_len ? (uint8_t)(tmp[whole] & (0xFF00u >> pv->bit_len)) : 0;
+        pv->ext_off = (uint16_t)pc.ext_exit;
+        free(tmp); tmp = NULL;
+        /* the new history and carry: bytes [c_exit - INC_HIST, n) of prefix + input */
+        {
+            const size_t from = pc.c_exit > INC_HIST ? pc.c_exit - INC_HIST : 0;
+            uint8_t keep[INC_HIST + INC_CARRY_MAX];
+            size_t k = 0;
+            for (size_t i = from; i < n; ) {
+                if (i < pv->data_len) { const size_t m = (pv->data_len < n ? pv->data_len : n) - i; memcpy(keep + k, pv->data + i, m); k += m; i += m; }
+                else { const size_t m = n - i; memcpy(keep + k, p->inPtr + (i - pv->data_len), m); k += m; i += m; }
+            }
+            memcpy(pv->data, keep, k);
+            pv->data_len = (uint32_t)k;
+            pv->carry_len = (uint32_t)(n - pc.c_exit);
+        }
+        p->inPtr += take; p->inLength -= take;
+        if (last) {
+            if (pv->pend_len) pv->marker_waiting = 1;
+            else p->status |= LZS_C_STATUS_END_MARKER;
+            break;
+        }
+        if (pv->pend_len || p->inLength == 0) break;
+    }
+    if (pv->pend_len) p->status |= LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
+    if (p->inLength == 0) p->status |= LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED;
+    return made;
+
+failed:
+    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+failed_quiet:
+    free(tmp);
+    p->status = LZS_C_STATUS_ERROR;
+    return made;
 }

@@ -1192,6 +1192,9 @@ struct WgJob {
     uint32_t *out_len;              // bytes written (a block), or null
     uint32_t *exit_pos;             // a segment: first token start >= cend ...
     unsigned long long *nbits;      // ... and the bits emitted up to there; or null
+    uint32_t *open_info;            // a piece of a stream that will go on (lzs_compress_incremental):
+                                    // {offset, start} of the job's last token if that is a match
+                                    // reaching the end of the data so far (n), {0, 0} otherwise; or null
 };
 
 __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgOut o)
@@ -1211,6 +1214,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
     L.bits[tid] = 0;
     __syncthreads();
 
+    if (job.open_info && tid == 0) { job.open_info[0] = 0; job.open_info[1] = 0; }
     uint32_t c = job.c0;         // start of the next token
     uint32_t loaded = job.w0;    // ring holds [loaded-4096, loaded)
     uint32_t next = job.w0;      // next batch of 64 positions to build
@@ -1267,7 +1271,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
               PROF_T1(16); }
             next = Se;
         }
-        const uint32_t send = Se < n ? Se : n;
+        const uint32_t send = Se < cend ? Se : cend;             // (cend <= n; tokens start before it)
         if (tid == 0) L.nextp = (!pending && c > Sb) ? c : Sb;
         __syncthreads();
         PROF_MARK(1);
@@ -1404,6 +1408,10 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
                 w = node[h] < 64u ? w : 0u;
                 const uint64_t v = w ? (((uint64_t)hv << tw) | tv) : 0ull;
                 valhi[h] = (uint32_t)(v >> 32); vallo[h] = (uint32_t)v; width[h] = w;
+                if (job.open_info) {                                       // (wave-uniform; null for whole blocks)
+                    const uint32_t pos = Pb + 256u * h + 64u * wave + (node[h] & 63u);
+                    if (w && len >= kTokenMax && pos + kTokenMax + ext == n) { job.open_info[0] = off; job.open_info[1] = pos; }
+                }
                 incl[h] = wave_inclusive_sum(w);
                 if (lane == 63u) L.chunk_bits[4 * h + wave] = incl[h];     // (exitfn is live: no dummy stores here)
             }
@@ -1489,6 +1497,7 @@ __device__ __forceinline__ void wg_compress_job(BlkLds &L, const WgJob &job, WgO
                     // on looks back at most 2047.
                     if (c > next + 2176u) next = (c - 2112u) & ~63u;
                     while (o.head >= 2048u) { wg_store_quarter(o, L, lane); o.flushed += 256u; o.head -= 2048u; }
+                    if (job.open_info && lane == 0 && c == n) { job.open_info[0] = off; job.open_info[1] = Pb + open_at; }
                     if (lane == 0) {
                         L.bcast[0] = c; L.bcast[1] = loaded; L.bcast[2] = next;
                         L.bcast[3] = o.flushed; L.bcast[4] = o.head;
@@ -1550,7 +1559,7 @@ void lzs_compress_blocks_wg_kernel(uint8_t *__restrict__ out, size_t out_stride,
     job.src = in + (size_t)b * in_stride;
     job.n = in_len ? in_len[b] : in_len_uniform;
     job.cend = job.n; job.c0 = 0; job.w0 = 0; job.last = true;
-    job.out_len = out_len + b; job.exit_pos = nullptr; job.nbits = nullptr;
+    job.out_len = out_len + b; job.exit_pos = nullptr; job.nbits = nullptr; job.open_info = nullptr;
     WgOut o;
     o.flushed = 0; o.head = 0;
     o.dst = out + (size_t)b * out_stride;
@@ -1573,14 +1582,18 @@ void lzs_compress_segments_kernel(uint8_t *__restrict__ slots, size_t slot_strid
                                   const uint8_t *__restrict__ in, uint32_t n, uint32_t seg, uint32_t nseg,
                                   const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
                                   uint32_t *__restrict__ exit_pos, unsigned long long *__restrict__ nbits,
-                                  uint8_t *__restrict__ out, const unsigned long long *__restrict__ bit_at)
+                                  uint8_t *__restrict__ out, const unsigned long long *__restrict__ bit_at,
+                                  uint32_t lim, uint32_t *__restrict__ open_info)
 {
     __shared__ BlkLds L;
     const uint32_t k = blockIdx.x;
     if (k >= nseg) return;
     if (dirty && !dirty[k]) return;
     const uint32_t s = k * seg;
-    const uint32_t e = s + seg < n ? s + seg : n;              // the last segment ends with the input
+    // The last segment ends with the input -- or, for a piece of a stream that will go on
+    // (lim < n), 15 bytes before it: a token is decided once 12 bytes of look-ahead are there,
+    // a length nibble once 15 are (lzs-compression.c:641-647, 750-758).
+    const uint32_t e = s + seg < lim ? s + seg : lim;
     WgJob job;
     job.src = in; job.n = n; job.cend = e;
     job.c0 = entry[k];
@@ -1590,8 +1603,12 @@ void lzs_compress_segments_kernel(uint8_t *__restrict__ slots, size_t slot_strid
     job.w0 = c64 > 2176u ? c64 - 2176u : 0u;
     job.last = false;
     job.out_len = nullptr; job.exit_pos = exit_pos + k; job.nbits = nbits + k;
+    job.open_info = open_info ? open_info + 2 * k : nullptr;
     if (job.c0 >= e) {                                         // the segment before ran over all of this one
-        if (threadIdx.x == 0) { exit_pos[k] = job.c0; nbits[k] = 0; }
+        if (threadIdx.x == 0) {
+            exit_pos[k] = job.c0; nbits[k] = 0;
+            if (open_info) { open_info[2 * k] = 0; open_info[2 * k + 1] = 0; }
+        }
         return;
     }
     WgOut o;
@@ -1617,7 +1634,7 @@ void lzs_compress_segments_kernel(uint8_t *__restrict__ slots, size_t slot_strid
 __global__ __launch_bounds__(256)
 void lzs_stitch_segments_kernel(uint8_t *__restrict__ out, const uint8_t *__restrict__ slots, size_t slot_stride,
                                 const unsigned long long *__restrict__ bit_at,
-                                const unsigned long long *__restrict__ nbits, uint32_t nseg)
+                                const unsigned long long *__restrict__ nbits, uint32_t nseg, uint32_t end_marker)
 {
     const uint32_t k = blockIdx.x;
     if (k >= nseg) return;
@@ -1635,13 +1652,67 @@ void lzs_stitch_segments_kernel(uint8_t *__restrict__ out, const uint8_t *__rest
         if (hi) atomicOr(dst + j, __builtin_bswap32(hi));
         if (lo) atomicOr(dst + j + 1, __builtin_bswap32(lo));
     }
-    if (k == nseg - 1u && threadIdx.x == 0) {                      // end marker after the last bit
+    if (end_marker && k == nseg - 1u && threadIdx.x == 0) {        // end marker after the last bit
         const unsigned long long end = at + nbits[k];
         const uint32_t s2 = (uint32_t)(end & 31ull);
         const unsigned long long m = (unsigned long long)0x180u << (64u - 9u - s2);   // 9 bits, left-aligned after s2
         unsigned int *d2 = reinterpret_cast<unsigned int *>(out) + (end >> 5);
         atomicOr(d2, __builtin_bswap32((uint32_t)(m >> 32)));
         if ((uint32_t)m) atomicOr(d2 + 1, __builtin_bswap32((uint32_t)m));
+    }
+}
+
+// A piece of a stream that begins inside a long match (lzs_compress_incremental: the call before
+// ended with the match still running, state COMPRESS_EXTENDED of lzs-compression.c:750-776).  One
+// wavefront measures how far in[c0..n) goes on repeating what lies `off` before it and writes the
+// length nibbles at bit `bit0` of the zeroed, 4-aligned `out`: 1111 for every 15 bytes, then the
+// closing nibble -- unless the run reaches the end of the data and more may follow (!last): then
+// only the full 15s are written and the match stays open.  result: {next position, still open,
+// bits written (low, high)}.
+__global__ __launch_bounds__(64)
+void lzs_extend_resume_kernel(uint8_t *__restrict__ out, uint32_t bit0, const uint8_t *__restrict__ in,
+                              uint32_t n, uint32_t c0, uint32_t off, uint32_t last, uint32_t *__restrict__ result)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t c = c0;
+    for (;;) {                                                     // 256 bytes a round, 4 per lane
+        const uint32_t q = c + 4u * lane;
+        uint32_t eq = 0;
+        while (eq < 4u && q + eq < n && in[q + eq] == in[q + eq - off]) eq++;
+        const uint64_t stops = __builtin_amdgcn_ballot_w64(eq < 4u);
+        if (stops) {
+            const uint32_t l = uniform((uint32_t)__builtin_ctzll(stops));
+            c += 4u * l + (uint32_t)__builtin_amdgcn_readlane((int)eq, (int)l);
+            break;
+        }
+        c += 256u;
+    }
+    const uint32_t run = c - c0;
+    const bool open = c == n && !last;
+    const uint32_t full = run / kNibbleMax;
+    const unsigned long long ones_end = (unsigned long long)bit0 + 4ull * full;
+    unsigned int *dst = reinterpret_cast<unsigned int *>(out);
+    for (unsigned long long w = (bit0 >> 5) + lane; w <= (ones_end >> 5) && 4ull * full; w += 64) {
+        const unsigned long long lo = w * 32ull > bit0 ? w * 32ull : bit0;
+        const unsigned long long hi = (w + 1ull) * 32ull < ones_end ? (w + 1ull) * 32ull : ones_end;
+        if (hi > lo) {
+            const uint32_t a = (uint32_t)(lo - w * 32ull), b = (uint32_t)(hi - w * 32ull);    // bits [a, b) of the word, MSB first
+            const uint32_t m = (~0u >> a) & (b == 32u ? ~0u : ~(~0u >> b));
+            atomicOr(dst + w, __builtin_bswap32(m));
+        }
+    }
+    if (!open && lane == 0) {
+        const uint32_t s2 = (uint32_t)(ones_end & 31ull);
+        const unsigned long long m = (unsigned long long)(run - kNibbleMax * full) << (64u - 4u - s2);
+        unsigned int *d2 = dst + (ones_end >> 5);
+        if ((uint32_t)(m >> 32)) atomicOr(d2, __builtin_bswap32((uint32_t)(m >> 32)));
+        if ((uint32_t)m) atomicOr(d2 + 1, __builtin_bswap32((uint32_t)m));
+    }
+    if (lane == 0) {
+        const unsigned long long bits = 4ull * full + (open ? 0ull : 4ull);
+        result[0] = open ? c0 + kNibbleMax * full : c;
+        result[1] = open ? 1u : 0u;
+        result[2] = (uint32_t)bits; result[3] = (uint32_t)(bits >> 32);
     }
 }
 
@@ -2575,24 +2646,34 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
 int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
-                                     void *d_out, const uint64_t *d_bit_at, void *stream)
+                                     void *d_out, const uint64_t *d_bit_at, uint32_t lim, uint32_t *d_open,
+                                     void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
                        (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
                        d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
-                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at);
+                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_extend_resume(void *d_out, uint32_t bit0, const void *d_in, uint32_t n, uint32_t c0,
+                                 uint32_t off, int last, uint32_t *d_result, void *stream)
+{
+    hipLaunchKernelGGL(lzs_extend_resume_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, bit0, (const uint8_t *)d_in, n, c0, off, last ? 1u : 0u, d_result);
     return (int)hipGetLastError();
 }
 
 int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot_stride,
                                    const uint64_t *d_bit_at, const uint64_t *d_nbits, uint32_t nseg,
-                                   void *stream)
+                                   int end_marker, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_stitch_segments_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream,
                        (uint8_t *)d_out, (const uint8_t *)d_slots, slot_stride,
-                       (const unsigned long long *)d_bit_at, (const unsigned long long *)d_nbits, nseg);
+                       (const unsigned long long *)d_bit_at, (const unsigned long long *)d_nbits, nseg,
+                       end_marker ? 1u : 0u);
     return (int)hipGetLastError();
 }
 

@@ -110,3 +110,107 @@ def test_decode_continues_after_end_markers_with_history():
     rng = random.Random(3)
     got, markers = _decode(stream, _rand(rng, 1, 300), _rand(rng, 1, 300), stop_at_markers=3)
     assert got == b"".join(packets) and markers == 3
+
+
+# ------------------------------------------------------------------ compression
+def _encode(data, in_chunks, out_chunks, finish=True, comp=None):
+    """Drive lzs_compress_incremental like c/src/utils/lzs-compress.c:91-134: input in pieces,
+    `finish` raised once all of it was taken and the compressor says it is starved."""
+    c = comp or lzs.IncrementalCompressor()
+    out, pos, pending, fin, status, calls = bytearray(), 0, b"", False, 0, 0
+    while True:
+        if not pending and not fin and pos < len(data):
+            pending = data[pos:pos + next(in_chunks)]
+            pos += len(pending)
+        if not pending and pos >= len(data) and (status & api.STATUS_INPUT_STARVED or not data):
+            if not finish:
+                break
+            fin = True
+        got, used, status = c.step(pending, next(out_chunks), fin)
+        calls += 1
+        out += got
+        pending = pending[used:]
+        if status & api.STATUS_END_MARKER:
+            break
+        if not finish and not pending and pos >= len(data) and not (status & api.STATUS_NO_OUTPUT_BUFFER_SPACE):
+            break
+        assert calls < 400000, "no progress"
+    return bytes(out), c
+
+
+def test_golden_vector_encoded_in_pieces():
+    comp, plain = golden_bytes("kat_compressed_1.bin"), golden_bytes("kat_decompressed_1.bin")
+    for ins, outs in ((_const(len(plain)), _const(1000)), (_const(10), _const(1000)), (_const(1000), _const(10)),
+                      (_const(1), _const(3)), (_const(512), _const(512)), (_const(7), _const(5))):
+        got, _ = _encode(plain, ins, outs)
+        assert got == comp
+
+
+@pytest.mark.parametrize("data,hexout", [
+    (b"", "c000"), (b"a", "30e000"), (b"aa", "30987000"), (b"a" * 9, "30e07c3000"),
+    (b"a" * 24, "30e07fc300"), (b"abcXabcYabc", "30988c658c2259c23800"),
+])
+def test_tiny_vectors_incremental(data, hexout):
+    for k in (1, 2, 100):
+        got, _ = _encode(data, _const(k), _const(100))
+        assert got.hex() == hexout
+
+
+@pytest.mark.parametrize("kind", ["text", "lowent", "random", "zeros", "mixed"])
+def test_encode_random_pieces_equals_one_shot(kind):
+    """Any chunking gives the one-shot stream (the reference's property; SURVEY.md §8f N3 probe)."""
+    rng = random.Random(17)
+    if kind == "mixed":
+        t = _sample("text", 200000)
+        plain = t[:50000] + bytes(70000) + t[50000:90000] + b"ab" * 40000 + _sample("random", 30000) + bytes(5)
+    else:
+        plain = _sample(kind, 300000)
+    want = O.compress(plain)
+    for lo, hi in ((1, 60), (100, 5000), (20000, 200000)):
+        got, _ = _encode(plain, _rand(rng, lo, hi), _rand(rng, max(lo, 3), hi))
+        assert got == want, (kind, lo, hi, len(got), len(want))
+
+
+def test_encode_one_big_call_uses_many_segments():
+    plain = _sample("text", 3 << 20)
+    got, _ = _encode(plain, _const(len(plain)), _const(4 << 20))
+    assert got == O.compress(plain)
+    got, _ = _encode(plain, _const(700001), _const(1 << 20))
+    assert got == O.compress(plain)
+
+
+def test_packets_with_history_kept_over_end_markers_equal_the_reference():
+    """RFC 1974 use: each packet is finished with an end marker and the SAME block goes on, so later
+    packets refer back into earlier ones.  Expected bytes: the reference's own incremental compressor
+    (tests/golden/make_incremental_golden.py)."""
+    packets = [golden_bytes("inc_packet_%d.bin" % i) for i in range(3)]
+    want = golden_bytes("inc_packets.lzs")
+    for chunk, space in ((512, 512), (100000, 100000), (33, 7)):
+        c, out = None, b""
+        for p in packets:
+            got, c = _encode(p, _const(chunk), _const(space), comp=c)
+            out += got
+        assert out == want, (chunk, space)
+
+
+def test_incremental_round_trip_through_both_directions():
+    rng = random.Random(23)
+    plain = _sample("lowent", 500000)
+    comp, _ = _encode(plain, _rand(rng, 1000, 50000), _rand(rng, 1000, 50000))
+    back, markers = _decode(comp, _rand(rng, 1000, 50000), _rand(rng, 1000, 50000))
+    assert back == plain and markers == 1
+
+
+# ------------------------------------------------------------------ the reference's tools on this library
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "dropin-lzs-compress")),
+                    reason="oracle/_ref/dropin-lzs-* were not built (needs /root/reference)")
+def test_reference_file_tools_built_on_this_library(tmp_path):
+    """c/src/utils/lzs-compress.c and lzs-decompress.c (512-byte reads through the incremental
+    interface) compiled against OUR header and linked with OUR library."""
+    plain = _sample("text", 150000)
+    src, comp, back = tmp_path / "in.bin", tmp_path / "in.lzs", tmp_path / "back.bin"
+    src.write_bytes(plain)
+    subprocess.run([os.path.join(REFDIR, "dropin-lzs-compress"), str(src), str(comp)], check=True, timeout=600)
+    assert comp.read_bytes() == O.compress(plain)
+    subprocess.run([os.path.join(REFDIR, "dropin-lzs-decompress"), str(comp), str(back)], check=True, timeout=600)
+    assert back.read_bytes() == plain
