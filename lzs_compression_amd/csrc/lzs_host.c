@@ -123,6 +123,7 @@ typedef struct {
     void  *stream;
     void  *buf[BUF_COUNT];
     size_t cap[BUF_COUNT];
+    uint8_t *host_box;              /* host side of the small incremental calls' single copies */
 } staging_t;
 
 static pthread_key_t  staging_key;
@@ -135,6 +136,7 @@ static void staging_destroy(void *p)
     for (int i = 0; i < BUF_COUNT; i++)
         if (st->buf[i]) lzs_hip_free(st->buf[i]);
     if (st->stream) lzs_hip_stream_destroy(st->stream);
+    free(st->host_box);
     free(st);
 }
 
@@ -315,8 +317,23 @@ static double now_ms(void)
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-#define STREAM_SEG   65536u
-#define STREAM_MIN   (2u * STREAM_SEG)          /* shorter inputs stay with one workgroup */
+#define STREAM_SEG_MAX 65536u
+#define STREAM_SEG_MIN 4096u
+#define STREAM_MIN   24576u                     /* shorter inputs stay with one workgroup */
+
+/* Segment size for a stream of n bytes: 64 KiB for long streams, smaller for shorter ones so that
+ * they too spread over the device -- a workgroup takes ~1.2 ms per 64 KiB, and every segment pays
+ * for a 2.2 KB warm-up of its chains.  Measured (text, host buffers, ms): 64 KiB 1.12 with one
+ * workgroup, 0.29 in 4 KiB segments; 1 MiB 1.38 in 64 KiB segments, 0.45 in 4 KiB ones; 4 MiB
+ * 2.84 / 1.05 (8 KiB); 16 MiB 5.17 / 4.13 (16 KiB). */
+static uint32_t stream_seg(size_t n)
+{
+    const char *v = getenv("LZS_STREAM_SEG");
+    size_t seg = v ? strtoul(v, NULL, 10) : (n / 512u + 4095u) & ~(size_t)4095u;
+    if (seg < STREAM_SEG_MIN) seg = STREAM_SEG_MIN;
+    if (seg > STREAM_SEG_MAX) seg = STREAM_SEG_MAX;
+    return (uint32_t)(seg & ~(size_t)63u);
+}
 
 /* in/out on the host (dev == 0: staged through this thread's device buffers) or on the device */
 /* A piece of a stream for lzs_compress_incremental(): the data is `prefix` (history and the
@@ -339,6 +356,7 @@ static size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t *in,
                                     piece_t *pc)
 {
     const char *who = pc ? "lzs_compress_incremental" : dev ? "lzs_compress_stream_device" : "lzs_compress";
+    const uint32_t STREAM_SEG = stream_seg(n);
     const uint32_t nseg = n ? (uint32_t)((n + STREAM_SEG - 1) / STREAM_SEG) : 1u;
     const size_t worst = LZS_COMPRESSED_MAX(n - (pc ? pc->c0 : 0)) + 8;
     const int end_marker = !pc || pc->last;
@@ -511,7 +529,7 @@ int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len, con
 
 size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
-    if (a_inLen > STREAM_MIN && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && !getenv("LZS_ONE_WORKGROUP"))
+    if ((a_inLen > STREAM_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && !getenv("LZS_ONE_WORKGROUP"))
         return stream_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
     return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
@@ -700,6 +718,10 @@ typedef struct __attribute__((packed)) {
     uint8_t  hist[LZS_MAX_HISTORY_SIZE];
 } dec_priv_t;
 #define DEC_PRIV_AT 36u
+#define DEC_SMALL     16384u        /* calls up to this much input and output take the short way */
+#define DEC_STATE_PAD 2112u         /* sizeof(lzs_dec_resume_t) rounded up to 64 */
+#define INC_BOX_BYTES (2 * (size_t)DEC_SMALL + DEC_STATE_PAD + 64)
+_Static_assert(sizeof(lzs_dec_resume_t) <= DEC_STATE_PAD, "state fits its slot");
 _Static_assert(sizeof(LzsDecompressParameters_t) == 2096, "size of the reference's LzsDecompressParameters_t");
 _Static_assert(sizeof(LzsCompressParameters_t) == 14432, "size of the reference's LzsCompressParameters_t");
 _Static_assert(DEC_PRIV_AT + sizeof(dec_priv_t) <= sizeof(LzsDecompressParameters_t), "private state fits");
@@ -745,24 +767,49 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
         const size_t most = 30u * (take + 4u) + 64u;
         const size_t cap = p->outLength < most ? p->outLength : most;
         void *d_in = NULL, *d_out = NULL, *d_state = NULL;
-        e = staging_reserve(st, BUF_IN, take + 64, &d_in);
-        if (!e) e = staging_reserve(st, BUF_OUT, cap + 64, &d_out);
-        if (!e) e = staging_reserve(st, BUF_AUX, sizeof(h), &d_state);
-        if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
         h.bitq = pv->bitq; h.qlen = pv->qlen; h.off = pv->off; h.rem = pv->rem;
         h.extended = pv->extended; h.hist_len = pv->hist_len;
         memcpy(h.hist, pv->hist, pv->hist_len);
-        HIP_TRY(lzs_hip_h2d(d_state, &h, sizeof(h), stream), "hipMemcpy H2D");
-        HIP_TRY(lzs_hip_h2d(d_in, p->inPtr, take, stream), "hipMemcpy H2D");
-        HIP_TRY(lzs_hip_launch_decode_resume((lzs_dec_resume_t *)d_state, d_in, (uint32_t)take, d_out, (uint32_t)cap, stream), who);
-        HIP_TRY(lzs_hip_d2h(&h, d_state, sizeof(h), stream), "hipMemcpy D2H");
-        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
-        if (h.in_used > take || h.out_made > cap || h.hist_len > LZS_MAX_HISTORY_SIZE) {
-            fail(LZS_E_HIP, "%s: inconsistent state from the device", who);
-            goto failed;
+        if (take <= DEC_SMALL && cap <= DEC_SMALL) {
+            /* A small call is all latency: one copy in ([input | state], the input right-aligned
+             * before the state), one launch, one copy out ([state | output]), one wait. */
+            if (!st->host_box) st->host_box = (uint8_t *)malloc(INC_BOX_BYTES);
+            uint8_t *box = st->host_box;
+            if (!box) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+            uint8_t *d_box = NULL;
+            e = staging_reserve(st, BUF_AUX, INC_BOX_BYTES, (void **)&d_box);
+            if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+            const size_t in_at = DEC_SMALL - ((take + 3u) & ~(size_t)3u);
+            memcpy(box + in_at, p->inPtr, take);
+            memcpy(box + DEC_SMALL, &h, sizeof(h));
+            HIP_TRY(lzs_hip_h2d(d_box + in_at, box + in_at, DEC_SMALL - in_at + sizeof(h), stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_launch_decode_resume((lzs_dec_resume_t *)(d_box + DEC_SMALL), d_box + in_at, (uint32_t)take,
+                                                 d_box + DEC_SMALL + DEC_STATE_PAD, (uint32_t)cap, stream), who);
+            HIP_TRY(lzs_hip_d2h(box + DEC_SMALL, d_box + DEC_SMALL, DEC_STATE_PAD + cap, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+            memcpy(&h, box + DEC_SMALL, sizeof(h));
+            if (h.in_used > take || h.out_made > cap || h.hist_len > LZS_MAX_HISTORY_SIZE) {
+                fail(LZS_E_HIP, "%s: inconsistent state from the device", who);
+                goto failed;
+            }
+            memcpy(p->outPtr, box + DEC_SMALL + DEC_STATE_PAD, h.out_made);
+        } else {
+            e = staging_reserve(st, BUF_IN, take + 64, &d_in);
+            if (!e) e = staging_reserve(st, BUF_OUT, cap + 64, &d_out);
+            if (!e) e = staging_reserve(st, BUF_AUX, sizeof(h), &d_state);
+            if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+            HIP_TRY(lzs_hip_h2d(d_state, &h, sizeof(h), stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_h2d(d_in, p->inPtr, take, stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_launch_decode_resume((lzs_dec_resume_t *)d_state, d_in, (uint32_t)take, d_out, (uint32_t)cap, stream), who);
+            HIP_TRY(lzs_hip_d2h(&h, d_state, sizeof(h), stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+            if (h.in_used > take || h.out_made > cap || h.hist_len > LZS_MAX_HISTORY_SIZE) {
+                fail(LZS_E_HIP, "%s: inconsistent state from the device", who);
+                goto failed;
+            }
+            HIP_TRY(lzs_hip_d2h(p->outPtr, d_out, h.out_made, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         }
-        HIP_TRY(lzs_hip_d2h(p->outPtr, d_out, h.out_made, stream), "hipMemcpy D2H");
-        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         pv->bitq = h.bitq; pv->qlen = (uint8_t)h.qlen; pv->off = (uint16_t)h.off; pv->rem = (uint8_t)h.rem;
         pv->extended = (uint8_t)h.extended; pv->hist_len = (uint16_t)h.hist_len;
         memcpy(pv->hist, h.hist, h.hist_len);

@@ -2429,11 +2429,24 @@ void lzs_decode_resume_kernel(lzs_dec_resume_t *__restrict__ st, const uint8_t *
     uint32_t count = base, flushed = base;
     const uint32_t limit = base + cap;
     uint32_t status = 0;
-    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in);   // staged 4-aligned, padded by the host
+    // The compressed input, 256 bytes (a word per lane) at a time and one batch ahead of use: a
+    // dependent global load per word would cost its full latency every 4 bytes.
+    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in);   // staged 4-aligned by the host
+    const uint32_t nwords = (n + 3u) >> 2;
+    uint32_t batch = 0;
+    uint32_t cur = lane < nwords ? in32[lane] : 0u;
+    uint32_t nxt = 64u + lane < nwords ? in32[64u + lane] : 0u;
 
     for (;;) {
         while (have <= 32 && ipos < n) {
-            uint32_t w = uniform(__builtin_bswap32(in32[ipos >> 2]));
+            const uint32_t wi = ipos >> 2;
+            if ((wi >> 6) != batch) {
+                batch = wi >> 6;
+                cur = nxt;
+                const uint32_t at = 64u * (batch + 1u) + lane;
+                nxt = at < nwords ? in32[at] : 0u;
+            }
+            uint32_t w = __builtin_bswap32((uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(wi & 63u)));
             const uint32_t nb = n - ipos < 4 ? n - ipos : 4;
             if (nb < 4) w &= ~0u << (8 * (4 - nb));
             bits |= (uint64_t)w << (32 - have);

@@ -76,6 +76,62 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert lib.lzs_last_error()
 
 
+def test_incremental_parameter_blocks_keep_the_reference_layout(tmp_path):
+    """LzsCompressParameters_t / LzsDecompressParameters_t: public members at the reference's
+    offsets, whole structs of the reference's sizes (c/src/liblzs/lzs.h:101-134, 180-211:
+    14432 and 2096 bytes with gcc on x86-64), the status flags with the reference's values
+    (:90-98, :168-176).  Where the reference is present, measured against its own header."""
+    prog = r'''
+#include <stddef.h>
+#include <stdio.h>
+#include "lzs.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu ", sizeof(LzsCompressParameters_t), offsetof(LzsCompressParameters_t, inPtr),
+           offsetof(LzsCompressParameters_t, outPtr), offsetof(LzsCompressParameters_t, inLength),
+           offsetof(LzsCompressParameters_t, outLength), offsetof(LzsCompressParameters_t, status));
+    printf("%zu %zu %zu %zu %zu %zu ", sizeof(LzsDecompressParameters_t), offsetof(LzsDecompressParameters_t, inPtr),
+           offsetof(LzsDecompressParameters_t, outPtr), offsetof(LzsDecompressParameters_t, inLength),
+           offsetof(LzsDecompressParameters_t, outLength), offsetof(LzsDecompressParameters_t, status));
+    printf("%d %d %d %d %d %d %d %d %d %d\n", LZS_C_STATUS_INPUT_STARVED, LZS_C_STATUS_INPUT_FINISHED, LZS_C_STATUS_END_MARKER,
+           LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE, LZS_C_STATUS_ERROR, LZS_D_STATUS_INPUT_STARVED, LZS_D_STATUS_INPUT_FINISHED,
+           LZS_D_STATUS_END_MARKER, LZS_D_STATUS_NO_OUTPUT_BUFFER_SPACE, LZS_D_STATUS_ERROR);
+    return 0;
+}
+'''
+    src = tmp_path / "layout.c"
+    src.write_text(prog)
+
+    def measure(incdir):
+        exe = tmp_path / ("layout_" + str(abs(hash(incdir))))
+        subprocess.run(["gcc", "-std=c99", f"-I{incdir}", str(src), "-o", str(exe)], check=True)
+        return subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+
+    ours = measure(f"{INC}/lzs")
+    assert ours == ["14432", "0", "8", "16", "24", "32", "2096", "0", "8", "16", "24", "32",
+                    "1", "2", "4", "8", "16", "1", "2", "4", "8", "16"]
+    ref_inc = "/root/reference/c/src/liblzs"
+    if os.path.exists(os.path.join(ref_inc, "lzs.h")):
+        assert measure(ref_inc) == ours
+    assert ctypes.sizeof(lzs.api.CompressParameters) == 14432 and ctypes.sizeof(lzs.api.DecompressParameters) == 2096
+
+
+def test_incremental_calls_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    c = lzs.IncrementalCompressor()
+    with pytest.raises(lzs.LzsError) as e:
+        c.step(b"hello hello hello hello hello", 100, True)
+    assert "no HIP device" in str(e.value)
+    d = lzs.IncrementalDecompressor()
+    with pytest.raises(lzs.LzsError):
+        d.step(bytes.fromhex("30e07c3000"), 100)
+    # nothing was consumed, nothing written
+    assert d.params.inLength == 5 and d.params.outLength == 100
+    # ... except what needs no codec: an empty call on an empty queue is just "starved"
+    assert lzs.IncrementalDecompressor().step(b"", 10) == (b"", 0, lzs.api.STATUS_INPUT_STARVED | lzs.api.STATUS_INPUT_FINISHED)
+
+
 def test_product_does_not_reference_the_oracle():
     """The shipped package and its native sources never import, link or open oracle/."""
     pkg = os.path.join(ROOT, "lzs_compression_amd")
