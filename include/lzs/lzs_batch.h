@@ -73,7 +73,7 @@ int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, 
  * already in HBM.  The stream is cut into 64 KiB segments, one workgroup each; where each
  * segment's first token starts is agreed in a few rounds and the segments' bits are shifted to
  * their global offsets, so the bytes are those of the one-shot call.
- * The 4-argument lzs_compress() takes the same route for inputs above 128 KiB.
+ * The 4-argument lzs_compress() takes the same route for inputs of 24 KiB and more.
  *
  * d_out must be 4-byte aligned and hold LZS_COMPRESSED_MAX(in_len) + 1024 bytes; ALL of that is
  * overwritten (cleared first).  The result is cut at out_cap as lzs_compress() does.  The call
