@@ -742,8 +742,9 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     int e = 0;
     p->status = LZS_D_STATUS_NONE;
     tls_error[0] = 0;
-    /* nothing to read and nothing queued: the answer needs no device (:475-478) */
-    if (p->inLength == 0 && pv->qlen == 0 && pv->rem == 0) {
+    /* nothing to read and no bit queued: the answer needs no device (:475-478; the reference
+     * stops there even with a copy pending) */
+    if (p->inLength == 0 && pv->qlen == 0) {
         p->status = LZS_D_STATUS_INPUT_FINISHED | LZS_D_STATUS_INPUT_STARVED;
         return 0;
     }
@@ -912,7 +913,7 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
     for (;;) {
         /* Take as much input as the room for its output allows: 9 bits a byte at worst, into the
          * caller's buffer and then into pend[]; one piece is at most 1 GiB. */
-        const size_t room = p->outLength + INC_PEND_MAX;
+        const size_t room = (p->outLength < ((size_t)1 << 40) ? p->outLength : ((size_t)1 << 40)) + INC_PEND_MAX;
         const size_t fits = (8u * room - 64u) / 9u - pv->carry_len;
         size_t take = p->inLength < fits ? p->inLength : fits;
         if (take > ((size_t)1 << 30)) take = (size_t)1 << 30;

@@ -2453,8 +2453,25 @@ void lzs_decode_resume_kernel(lzs_dec_resume_t *__restrict__ st, const uint8_t *
             have += 8 * nb;
             ipos += 4;
         }
-        if (rem == 0) {
-            if (have == 0) { status |= LZS_INC_INPUT_FINISHED | LZS_INC_INPUT_STARVED; break; }   // :475-478
+        // No bit left: the reference stops here whatever it was doing (:475-478, :492-496) -- also
+        // with a copy pending, which then waits for the next call that brings input.
+        if (have == 0) { status |= LZS_INC_INPUT_FINISHED | LZS_INC_INPUT_STARVED; break; }
+        if (rem) {                                                 // :640-704
+            const uint32_t room = limit - count;
+            if (room == 0) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
+            const uint32_t m = rem < room ? rem : room;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t v = 0;
+            if (lane < m) {
+                const uint32_t k = off > 15u ? lane : lane % off;
+                const uint32_t from = count + k;
+                v = from >= off ? ring8[(from - off) & kRingMask] : 0u;   // before the history's start -> 0 (:676-683)
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < m) ring8[(count + lane) & kRingMask] = (uint8_t)v;
+            count += m;
+            rem -= m;
+        } else {
             bool starved = false;
             if (extended) {                                        // :706-723
                 if (have < 4) starved = true;
@@ -2506,22 +2523,6 @@ void lzs_decode_resume_kernel(lzs_dec_resume_t *__restrict__ st, const uint8_t *
                 }
             }
             if (starved) { status |= LZS_INC_INPUT_STARVED; break; }     // the token's bits stay queued
-        }
-        if (rem) {                                                 // :640-704
-            const uint32_t room = limit - count;
-            if (room == 0) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
-            const uint32_t m = rem < room ? rem : room;
-            __builtin_amdgcn_wave_barrier();
-            uint32_t v = 0;
-            if (lane < m) {
-                const uint32_t k = off > 15u ? lane : lane % off;
-                const uint32_t from = count + k;
-                v = from >= off ? ring8[(from - off) & kRingMask] : 0u;   // before the history's start -> 0 (:676-683)
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < m) ring8[(count + lane) & kRingMask] = (uint8_t)v;
-            count += m;
-            rem -= m;
         }
         if (count - flushed >= kTile) {
             __builtin_amdgcn_wave_barrier();

@@ -3,6 +3,8 @@
 built by `make -C oracle ref`; build container only).
 
   inc_packet_0.bin .. inc_packet_2.bin   three inputs; the later ones repeat parts of the earlier
+  inc_garbage.json                       random bytes -> what the reference's lzs_decompress_incremental()
+                                         makes of them (output and number of end markers)
   inc_packets.lzs                        what the reference's lzs_compress_incremental() writes for
                                          them when each is finished with an end marker and the SAME
                                          parameter block goes on to the next (history kept, RFC 1974
@@ -79,7 +81,79 @@ def ref_decompress_all(stream, markers):
     return bytes(out)
 
 
+def has_long_offset_zero(stream):
+    """Walk the tokens (RFC 1974 format) and say whether a match token with the 11-bit offset 0
+    occurs: for that malformed token the reference's one-shot and incremental decoders disagree
+    with each other (lzs-decompression.c:280 skips the length field, :584-592 does not), and this
+    library follows the one-shot rule, so such streams are left out of the fixture."""
+    bits = "".join(format(b, "08b") for b in stream)
+    i, ext = 0, False
+    while i < len(bits):
+        if ext:
+            if i + 4 > len(bits):
+                return False
+            ext = bits[i:i + 4] == "1111"
+            i += 4
+        elif bits[i] == "0":
+            i += 9
+        else:
+            if i + 2 > len(bits):
+                return False
+            short = bits[i + 1] == "1"
+            w = 7 if short else 11
+            if i + 2 + w > len(bits):
+                return False
+            off = int(bits[i + 2:i + 2 + w], 2)
+            i += 2 + w
+            if off == 0:
+                if not short:
+                    return True
+                i += (-i) % 8                     # end marker: realign
+                continue
+            if i + 2 > len(bits):
+                return False
+            if bits[i:i + 2] != "11":
+                i += 2
+            else:
+                if i + 4 > len(bits):
+                    return False
+                ext = bits[i:i + 4] == "1111"
+                i += 4
+    return False
+
+
+def garbage_vectors():
+    """Random bytes through the REFERENCE's incremental decoder (4096 bytes of output space a call,
+    until the input is used up): what a decoder does with nonsense is part of its behaviour."""
+    import json
+    import numpy as np
+    rng = np.random.default_rng(77)
+    REF.lzs_decompress_init.argtypes = [ctypes.c_void_p]
+    vecs, skipped = [], 0
+    for i in range(96):
+        n = int(rng.integers(1, 120))
+        lo = 128 if i % 3 == 0 else 0            # a third biased towards match tokens
+        stream = bytes(rng.integers(lo, 256, n, dtype=np.uint8))
+        if has_long_offset_zero(stream):
+            skipped += 1
+            continue
+        b = Block(2096, REF.lzs_decompress_init)
+        out, pending, markers, calls = bytearray(), stream, 0, 0
+        while True:
+            got, used, status = b.call(REF.lzs_decompress_incremental, pending, 4096)
+            out += got
+            pending = pending[used:]
+            markers += 1 if status & END_MARKER else 0
+            calls += 1
+            if (not pending and (status & STARVED)) or calls > 10000 or len(out) > (1 << 20):
+                break
+        vecs.append({"in": stream.hex(), "out": bytes(out).hex(), "markers": markers})
+    json.dump(vecs, open(os.path.join(HERE, "inc_garbage.json"), "w"), indent=0)
+    print("garbage vectors:", len(vecs), "kept,", skipped, "with a long offset 0 left out")
+
+
 def main():
+    garbage_vectors()
     text = workload.fill(workload.CLASS_NAMES.index("text"), 1, 65536, first_block=3, seed=workload.DEFAULT_SEED).tobytes()
     p0 = text[:3000]
     p1 = text[1200:2000] + b"\x00" * 100 + text[100:700]            # reaches back into p0

@@ -214,3 +214,17 @@ def test_reference_file_tools_built_on_this_library(tmp_path):
     assert comp.read_bytes() == O.compress(plain)
     subprocess.run([os.path.join(REFDIR, "dropin-lzs-decompress"), str(comp), str(back)], check=True, timeout=600)
     assert back.read_bytes() == plain
+
+
+def test_garbage_decodes_like_the_reference_incremental_decoder():
+    """Random bytes: same output and the same number of end markers as the reference's
+    lzs_decompress_incremental() (tests/golden/inc_garbage.json), whole and in small pieces."""
+    import json
+    vecs = json.load(open(os.path.join(ROOT, "tests", "golden", "inc_garbage.json")))
+    assert len(vecs) >= 60
+    rng = random.Random(5)
+    for v in vecs:
+        stream, want = bytes.fromhex(v["in"]), bytes.fromhex(v["out"])
+        for ins, outs in ((_const(len(stream)), _const(4096)), (_rand(rng, 1, 9), _rand(rng, 1, 50))):
+            got, markers = _decode(stream, ins, outs)
+            assert got == want and markers == v["markers"], v["in"]
