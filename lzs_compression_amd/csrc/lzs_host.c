@@ -116,7 +116,7 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
 /* Each host thread keeps one HIP stream and four grow-only device buffers for the host-buffer
  * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
  * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
-enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_COUNT };
+enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_MARKS, BUF_COUNT };
 #define KEEP_MAX ((size_t)256 << 20)
 
 typedef struct {
@@ -544,7 +544,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
     const uint32_t nseg = (uint32_t)((n + seg - 1) / seg);
     size_t result = 0;
     int e = 0, rc = LZS_OK;
-    void *d_in = NULL, *d_out = NULL, *d_aux = NULL, *d_origin = NULL;
+    void *d_in = NULL, *d_out = NULL, *d_aux = NULL, *d_origin = NULL, *d_marks = NULL;
     uint32_t *entry = NULL, *exits = NULL, *count = NULL, *start = NULL;
     uint8_t *dirty = NULL, *ones = NULL;
     uint32_t *seen = NULL;
@@ -567,6 +567,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
     const size_t aux_bytes = (size_t)nseg * (4 + 4 + 4 + 4 + 1 + 1) + 128;
     if (dev) d_in = (void *)in; else e = staging_reserve(st, BUF_IN, n + 64, &d_in);
     if (!e) e = staging_reserve(st, BUF_AUX, aux_bytes, &d_aux);
+    if (!e) e = staging_reserve(st, BUF_MARKS, (size_t)nseg * LZS_SCAN_MARK_WORDS * 4u, &d_marks);
     if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
     uint32_t *d_entry = (uint32_t *)d_aux;
     uint32_t *d_exit = d_entry + nseg;
@@ -585,7 +586,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");

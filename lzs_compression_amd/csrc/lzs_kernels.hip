@@ -2100,6 +2100,7 @@ constexpr uint32_t kDecEnd   = 8u * kDecSeg;          // its length in bits
 constexpr uint32_t kClean    = 0xFFFFFFFFu;           // origin: the byte is final
 constexpr uint32_t kDoneBase = 0xFFFFFF00u;           // origin: resolved in round (value & 0xFF)
 constexpr uint32_t kSegStop  = 1u << 30;              // state word: the stream ended in this segment
+constexpr uint32_t kScanMarkWords = 132;              // per segment: 64 marks, 64 byte counts, exit state, total, pad
 // state word: bits 0..7 cursor past the segment start (bits), bit 8 extension running, 9..19 offset
 
 // In LDS an origin is how far BEFORE the segment's output it lies (1..2047: a copy can only reach
@@ -2114,8 +2115,25 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                                                    uint32_t *exit_out, uint32_t *count_out,
                                                    uint8_t *out, uint32_t cap, uint32_t out_start,
                                                    uint32_t *origin_g, uint32_t *tainted_total,
-                                                   DecSegLds *Lp, uint32_t lane)
+                                                   DecSegLds *Lp, uint32_t lane,
+                                                   uint32_t *marks = nullptr, bool compare = false)
 {
+    // SCAN only.  A walk that is repeated from another entry falls in step with the walk before
+    // after a few dozen tokens, and from there on it IS that walk: a full walk leaves behind its
+    // first 64 token starts (state word and bytes produced so far: `marks`), and a repeated one
+    // stops as soon as it stands on one of them -- it leaves as the full walk left, with that
+    // walk's byte count from there on.  (Otherwise every round costs a walk over all 8 KiB.)
+    uint32_t my_mark = ~0u, my_count = 0, nmark = 0;
+    uint32_t old_mark = ~0u, old_count = 0, old_last = 0;
+    bool checking = false, merged = false;
+    if (!DECODE && compare) {
+        old_mark = marks[lane]; old_count = marks[64u + lane];
+        const uint64_t valid = __builtin_amdgcn_ballot_w64(old_mark != ~0u);
+        if (valid) {
+            checking = true;
+            old_last = (uint32_t)__builtin_amdgcn_readlane((int)old_mark, 63 - (int)__builtin_clzll(valid)) & 0xFFFFu;
+        }
+    }
     uint8_t *ring8 = DECODE ? reinterpret_cast<uint8_t *>(Lp->ring) : nullptr;
     uint16_t *origin = DECODE ? Lp->origin : nullptr;
     const uint32_t rel0 = entry & 0xFFu;
@@ -2159,6 +2177,25 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                 // that fell in step would still look different to the host)
                 state = (cur - kDecEnd) | (extended << 8) | ((extended ? off : 0u) << 9);
                 break;
+            }
+            if (!DECODE && marks) {
+                const uint32_t word = cur | (extended << 16) | ((extended ? off : 0u) << 17);
+                if (checking) {
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(old_mark == word);
+                    if (hit) {
+                        const uint32_t j = uniform((uint32_t)__builtin_ctzll(hit));
+                        state = marks[128];
+                        count += marks[129] - (uint32_t)__builtin_amdgcn_readlane((int)old_count, (int)j);
+                        merged = true;
+                        break;
+                    }
+                    if (cur > old_last) checking = false;
+                }
+                if (nmark < 64u) {
+                    my_mark = lane == nmark ? word : my_mark;
+                    my_count = lane == nmark ? count : my_count;
+                    nmark++;
+                }
             }
             if (have == 0u) break;                               // input exhausted (:189)
             if (DECODE && out_start + count >= cap) break;       // output full (:200)
@@ -2269,9 +2306,15 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
             if (g < cap && g >= out_start) { out[g] = ring8[p & kRingMask]; origin_g[g] = og ? out_start - og : kClean; tainted += og != 0u; }
         }
         if (tainted) atomicAdd(tainted_total, tainted);
-    } else if (lane == 0) {
-        *exit_out = state;
-        *count_out = count;
+    } else {
+        if (marks && !merged) {
+            marks[lane] = my_mark; marks[64u + lane] = my_count;
+            if (lane == 0) { marks[128] = state; marks[129] = count; }
+        }
+        if (lane == 0) {
+            *exit_out = state;
+            *count_out = count;
+        }
     }
 }
 
@@ -2279,7 +2322,7 @@ __global__ __launch_bounds__(256)
 void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
                             const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
                             uint32_t *__restrict__ exit_state, uint32_t *__restrict__ count,
-                            uint8_t *__restrict__ all_ones)
+                            uint8_t *__restrict__ all_ones, uint32_t *__restrict__ marks, uint32_t compare)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * 4u + uniform(threadIdx.x >> 6);
@@ -2298,7 +2341,8 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
     }
     if (dirty && !dirty[k]) return;
     lzs_stream_segment<false>(in, n, k, uniform(entry[k]), exit_state + k, count + k,
-                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane);
+                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane,
+                              marks ? marks + (size_t)k * kScanMarkWords : nullptr, compare != 0u);
 }
 
 __global__ __launch_bounds__(256)
@@ -2693,11 +2737,12 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
 
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
-                               uint8_t *d_all_ones, void *stream)
+                               uint8_t *d_all_ones, uint32_t *d_marks, int compare, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones);
+                       (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones,
+                       d_marks, compare ? 1u : 0u);
     return (int)hipGetLastError();
 }
 
