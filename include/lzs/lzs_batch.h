@@ -89,7 +89,7 @@ int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
  * the first end marker, at out_cap, or when the bits run out).  The stream is cut into 8 KiB
  * segments that agree on the decoder state at their borders in a few rounds, decode with per-byte
  * origins for copies reaching into another segment's output, and resolve those by pointer jumping
- * (DESIGN.md 3.6).  The 4-argument lzs_decompress() takes the same route above 256 KiB.  Output
+ * (DESIGN.md 3.6).  The 4-argument lzs_decompress() takes the same route from 4 KiB of input on.  Output
  * below 4 GiB; allocates 4 * produced bytes of scratch on this thread's staging; synchronous.
  */
 int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len,

@@ -62,14 +62,15 @@ int lzs_hip_launch_extend_resume(void *d_out, uint32_t bit0, const void *d_in, u
 /* One long stream decompressed by many wavefronts (lzs_scan_stream_kernel, lzs_decode_stream_kernel,
  * lzs_resolve_stream_kernel; state words and the scheme are described at the kernels). */
 #define LZS_SEG_STOP (1u << 30)
-unsigned lzs_hip_dec_segment_bytes(void);
+unsigned lzs_hip_dec_segment_bytes(void);             /* the largest segment (long streams) */
 #define LZS_SCAN_MARK_WORDS 132u     /* per segment in d_marks: what a full walk leaves for repeated ones */
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
-                               uint8_t *d_all_ones /* or NULL */, uint32_t *d_marks, int compare, void *stream);
+                               uint8_t *d_all_ones /* or NULL */, uint32_t *d_marks, int compare,
+                               uint32_t seg, void *stream);
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
-                                 const uint32_t *d_out_start, void *stream);
+                                 const uint32_t *d_out_start, uint32_t seg, void *stream);
 int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
                                   uint32_t *d_left, void *stream);
 /* The incremental entry points (lzs_incremental.c).  Status bits as in the reference's

@@ -320,6 +320,7 @@ static double now_ms(void)
 #define STREAM_SEG_MAX 65536u
 #define STREAM_SEG_MIN 4096u
 #define STREAM_MIN   24576u                     /* shorter inputs stay with one workgroup */
+#define STREAM_DEC_MIN 4096u                    /* shorter streams are decompressed by one wavefront */
 
 /* Segment size for a stream of n bytes: 64 KiB for long streams, smaller for shorter ones so that
  * they too spread over the device -- a workgroup takes ~1.2 ms per 64 KiB, and every segment pays
@@ -534,13 +535,28 @@ size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *
     return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
 
+/* Segment size for decompressing a stream of n compressed bytes: 8 KiB for long streams, smaller
+ * for short ones so that they too are spread over many wavefronts (one wavefront decodes ~7 MB/s).
+ * Measured (text, host buffers, ms; output size): 64 KiB 7.7 with one wavefront, 0.67 in 256-byte
+ * segments; 256 KiB 30.8 / 1.0; 1 MiB 122.8 / 2.4 (6.3 in 8 KiB segments); 4 MiB 8.2 in 1 KiB
+ * segments, 10.1 in 8 KiB ones. */
+static uint32_t stream_dec_seg(size_t n)
+{
+    const char *v = getenv("LZS_DEC_SEG");
+    size_t seg = v ? strtoul(v, NULL, 10) : (n / 2048u + 255u) & ~(size_t)255u;
+    const size_t most = lzs_hip_dec_segment_bytes();
+    if (seg < 256u) seg = 256u;
+    if (seg > most) seg = most;
+    return (uint32_t)(seg & ~(size_t)63u);
+}
+
 /* lzs_decompress() of one long stream by many wavefronts: see lzs_scan_stream_kernel.  Returns
  * SIZE_MAX if this path does not apply (output of 4 GiB or more) and the caller should decode
  * with one wavefront. */
 static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status)
 {
     const char *who = dev ? "lzs_decompress_stream_device" : "lzs_decompress";
-    const uint32_t seg = lzs_hip_dec_segment_bytes();
+    const uint32_t seg = stream_dec_seg(n);
     const uint32_t nseg = (uint32_t)((n + seg - 1) / seg);
     size_t result = 0;
     int e = 0, rc = LZS_OK;
@@ -586,7 +602,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0, seg, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
@@ -645,7 +661,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
         HIP_TRY(lzs_hip_launch_decode_stream(d_out, produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
-                                             nseg, d_entry, d_start, stream), who);
+                                             nseg, d_entry, d_start, seg, stream), who);
         uint32_t open[2] = {0, 0};
         HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -694,8 +710,8 @@ int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len, c
 
 size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
-    if (a_inLen > 262144u && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && a_outBufferSize &&
-        !getenv("LZS_ONE_WAVE")) {
+    if ((a_inLen > STREAM_DEC_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX &&
+        a_pOutData && a_pInData && a_outBufferSize && !getenv("LZS_ONE_WAVE")) {
         const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
         if (got != SIZE_MAX) return got;
     }

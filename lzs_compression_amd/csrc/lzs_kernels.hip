@@ -2079,7 +2079,7 @@ void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_strid
 
 // ---------------------------------------------------------------------------------
 // ONE long stream decompressed by many wavefronts (the counterpart of the segment compressor).
-// The compressed stream is cut into segments of kDecSeg bytes, one wave each.  What a segment
+// The compressed stream is cut into segments of `seg` bytes (kDecSeg below), one wave each.  What a segment
 // cannot know by itself is the decoder's state when its bit cursor first crosses into it: the bit
 // where the first token starts, whether an extension is running and at which offset.  So:
 //   SCAN    every segment walks its tokens without copying anything, entered at its first bit in
@@ -2095,8 +2095,8 @@ void lzs_decompress_blocks_v2_kernel(uint8_t *__restrict__ out, size_t out_strid
 //           value, otherwise it adopts its origin's origin) until none is left.
 // Stop rules as in lzs_decompress_blocks_v2_kernel, one-shot form (the first end marker ends it).
 // ---------------------------------------------------------------------------------
-constexpr uint32_t kDecSeg   = 8192;                  // compressed bytes per segment (a wave walks it in ~1 ms)
-constexpr uint32_t kDecEnd   = 8u * kDecSeg;          // its length in bits
+constexpr uint32_t kDecSegMax = 8192;                 // compressed bytes per segment of a long stream (a wave walks it in
+                                                      // ~1 ms); short streams take smaller ones (the host chooses `seg`)
 constexpr uint32_t kClean    = 0xFFFFFFFFu;           // origin: the byte is final
 constexpr uint32_t kDoneBase = 0xFFFFFF00u;           // origin: resolved in round (value & 0xFF)
 constexpr uint32_t kSegStop  = 1u << 30;              // state word: the stream ended in this segment
@@ -2115,9 +2115,10 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                                                    uint32_t *exit_out, uint32_t *count_out,
                                                    uint8_t *out, uint32_t cap, uint32_t out_start,
                                                    uint32_t *origin_g, uint32_t *tainted_total,
-                                                   DecSegLds *Lp, uint32_t lane,
+                                                   DecSegLds *Lp, uint32_t lane, uint32_t kDecSeg,
                                                    uint32_t *marks = nullptr, bool compare = false)
 {
+    const uint32_t kDecEnd = 8u * kDecSeg;                        // the segment's length in bits
     // SCAN only.  A walk that is repeated from another entry falls in step with the walk before
     // after a few dozen tokens, and from there on it IS that walk: a full walk leaves behind its
     // first 64 token starts (state word and bytes produced so far: `marks`), and a repeated one
@@ -2322,7 +2323,8 @@ __global__ __launch_bounds__(256)
 void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
                             const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
                             uint32_t *__restrict__ exit_state, uint32_t *__restrict__ count,
-                            uint8_t *__restrict__ all_ones, uint32_t *__restrict__ marks, uint32_t compare)
+                            uint8_t *__restrict__ all_ones, uint32_t *__restrict__ marks, uint32_t compare,
+                            uint32_t kDecSeg)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * 4u + uniform(threadIdx.x >> 6);
@@ -2341,7 +2343,7 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
     }
     if (dirty && !dirty[k]) return;
     lzs_stream_segment<false>(in, n, k, uniform(entry[k]), exit_state + k, count + k,
-                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane,
+                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane, kDecSeg,
                               marks ? marks + (size_t)k * kScanMarkWords : nullptr, compare != 0u);
 }
 
@@ -2349,7 +2351,8 @@ __global__ __launch_bounds__(256)
 void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t *__restrict__ origin_g,
                               uint32_t *__restrict__ tainted_total,
                               const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
-                              const uint32_t *__restrict__ entry, const uint32_t *__restrict__ out_start)
+                              const uint32_t *__restrict__ entry, const uint32_t *__restrict__ out_start,
+                              uint32_t kDecSeg)
 {
     __shared__ DecSegLds lds[4];
     const uint32_t lane = threadIdx.x & 63u;
@@ -2359,7 +2362,7 @@ void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t 
     const uint32_t e = uniform(entry[k]);
     if (e & kSegStop) return;                                 // the stream ended before this segment
     lzs_stream_segment<true>(in, n, k, e, nullptr, nullptr, out, cap, uniform(out_start[k]),
-                             origin_g, tainted_total, &lds[wv], lane);
+                             origin_g, tainted_total, &lds[wv], lane, kDecSeg);
 }
 
 // One round of pointer jumping over the origins (each launch only trusts what earlier launches
@@ -2737,22 +2740,22 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
 
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
-                               uint8_t *d_all_ones, uint32_t *d_marks, int compare, void *stream)
+                               uint8_t *d_all_ones, uint32_t *d_marks, int compare, uint32_t seg, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones,
-                       d_marks, compare ? 1u : 0u);
+                       d_marks, compare ? 1u : 0u, seg);
     return (int)hipGetLastError();
 }
 
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
-                                 const uint32_t *d_out_start, void *stream)
+                                 const uint32_t *d_out_start, uint32_t seg, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start);
+                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg);
     return (int)hipGetLastError();
 }
 
@@ -2767,7 +2770,7 @@ int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t tota
     return (int)hipGetLastError();
 }
 
-unsigned lzs_hip_dec_segment_bytes(void) { return kDecSeg; }
+unsigned lzs_hip_dec_segment_bytes(void) { return kDecSegMax; }
 
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks, void *stream)

@@ -420,7 +420,7 @@ def test_stream_device_entry_point_1gib_text():
 
 
 def test_one_long_stream_decompressed_by_many_wavefronts():
-    """lzs_decompress() of a stream longer than 256 KiB is cut into 8 KiB segments, one wavefront
+    """lzs_decompress() of a long stream is cut into 8 KiB segments, one wavefront
     each: the segments agree on the decoder state at their borders in a few rounds, decode with
     per-byte origins for copies that reach into another segment's output, and resolve those by
     pointer jumping.  Same bytes and the same stop rules as one wavefront: every class, a mixture
@@ -446,7 +446,6 @@ def test_one_long_stream_decompressed_by_many_wavefronts():
     datas.append(bytes(mix))
     for d in datas:
         comp = O.compress(d)
-        assert len(comp) > 262144 or d is datas[1]            # (the low-entropy class may stay below the threshold)
         assert lzs.decompress(comp, len(d) + 5) == d
         assert lzs.decompress(comp, len(d) // 3) == d[: len(d) // 3]
         assert lzs.decompress(comp[: len(comp) // 2], len(d)) == O.decompress(comp[: len(comp) // 2], len(d))
@@ -457,6 +456,41 @@ def test_one_long_stream_decompressed_by_many_wavefronts():
             assert lzs.decompress(junk, cap) == O.decompress(junk, cap)
     ones = bytes([0xFF]) * 400_000                            # an endless extension (offset 127)
     assert lzs.decompress(ones, 3_000_000) == O.decompress(ones, 3_000_000)
+
+
+def test_short_streams_decompressed_by_many_wavefronts_in_small_segments():
+    """From 4 KiB of compressed input on, lzs_decompress() spreads a stream over many wavefronts in
+    segments sized to the stream (256 bytes for short ones: a 64 KiB block takes 0.7 ms instead of
+    7.7).  Same bytes and stop rules as the oracle at every size: whole, cut capacity, truncated
+    input, data after the end marker, garbage, all-0xFF, long runs."""
+    rng = np.random.default_rng(5)
+    text = bytes(workload.fill("text", 8).reshape(-1))
+    rnd = bytes(workload.fill("random", 4).reshape(-1))
+    low = bytes(workload.fill("lowent", 40).reshape(-1))
+    datas = []
+    for n in (7000, 9000, 16384, 65536, 65537, 100_000, 262_144, 500_001):
+        datas.append(text[:n])
+    datas += [rnd[:5000], rnd[:40_000], rnd[:200_001], low[:150_000], low[: 40 * 65536], bytes(300_000),
+              text[:3000] + bytes(50_000) + text[3000:9000] + b"xy" * 30_000 + rnd[:7000]]
+    walked = 0
+    for d in datas:
+        comp = O.compress(d)
+        walked += len(comp) >= 4096
+        assert lzs.decompress(comp, len(d) + 5) == d
+        assert lzs.decompress(comp, len(d)) == d
+        for cap in (1, len(d) // 3, len(d) - 1):
+            assert lzs.decompress(comp, cap) == d[:cap]
+        for cut in (len(comp) // 2, len(comp) - 1, len(comp) - 2, len(comp) - 3):
+            assert lzs.decompress(comp[:cut], len(d)) == O.decompress(comp[:cut], len(d))
+        assert lzs.decompress(comp + comp[:3000], len(d) + 5) == d
+    assert walked >= 12
+    for _ in range(12):
+        junk = bytes(rng.integers(0, 256, int(rng.integers(4096, 120_000)), dtype=np.uint8))
+        for cap in (777, 2_000_000):
+            assert lzs.decompress(junk, cap) == O.decompress(junk, cap)
+    for n in (4096, 5000, 70_000):
+        ones = bytes([0xFF]) * n
+        assert lzs.decompress(ones, 30 * n + 100) == O.decompress(ones, 30 * n + 100)
 
 
 @pytest.mark.parametrize("variant", ["chain", "scan"])
