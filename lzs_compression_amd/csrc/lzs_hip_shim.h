@@ -67,10 +67,10 @@ unsigned lzs_hip_dec_segment_bytes(void);             /* the largest segment (lo
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones /* or NULL */, uint32_t *d_marks, int compare,
-                               uint32_t seg, void *stream);
+                               uint32_t seg, int concat /* go on after end markers */, void *stream);
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
-                                 const uint32_t *d_out_start, uint32_t seg, void *stream);
+                                 const uint32_t *d_out_start, uint32_t seg, int concat, void *stream);
 int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
                                   uint32_t *d_left, void *stream);
 /* The incremental entry points (lzs_incremental.c).  Status bits as in the reference's

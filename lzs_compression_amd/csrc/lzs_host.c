@@ -553,9 +553,9 @@ static uint32_t stream_dec_seg(size_t n)
 /* lzs_decompress() of one long stream by many wavefronts: see lzs_scan_stream_kernel.  Returns
  * SIZE_MAX if this path does not apply (output of 4 GiB or more) and the caller should decode
  * with one wavefront. */
-static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status)
+static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, int concat)
 {
-    const char *who = dev ? "lzs_decompress_stream_device" : "lzs_decompress";
+    const char *who = dev ? "lzs_decompress_stream_device" : concat ? "lzs_decompress_concat" : "lzs_decompress";
     const uint32_t seg = stream_dec_seg(n);
     const uint32_t nseg = (uint32_t)((n + seg - 1) / seg);
     size_t result = 0;
@@ -602,7 +602,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0, seg, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0, seg, concat, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
@@ -661,7 +661,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
         HIP_TRY(lzs_hip_launch_decode_stream(d_out, produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
-                                             nseg, d_entry, d_start, seg, stream), who);
+                                             nseg, d_entry, d_start, seg, concat, stream), who);
         uint32_t open[2] = {0, 0};
         HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -702,7 +702,7 @@ int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len, c
     if (in_len == 0 || out_cap == 0) return LZS_OK;
     if (in_len > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "lzs_decompress_stream_device: stream exceeds LZS_BLOCK_MAX");
     int rc = LZS_OK;
-    const size_t got = stream_decompress((uint8_t *)d_out, out_cap, (const uint8_t *)d_in, in_len, 1, &rc);
+    const size_t got = stream_decompress((uint8_t *)d_out, out_cap, (const uint8_t *)d_in, in_len, 1, &rc, 0);
     if (got == SIZE_MAX) return fail(LZS_E_ARG, "lzs_decompress_stream_device: output of 4 GiB or more");
     *out_len = got;
     return rc;
@@ -712,7 +712,7 @@ size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t
 {
     if ((a_inLen > STREAM_DEC_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX &&
         a_pOutData && a_pInData && a_outBufferSize && !getenv("LZS_ONE_WAVE")) {
-        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
+        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL, 0);
         if (got != SIZE_MAX) return got;
     }
     return one_shot("lzs_decompress", lzs_hip_launch_decompress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
@@ -720,6 +720,11 @@ size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t
 
 size_t lzs_decompress_concat(uint8_t *out, size_t out_cap, const uint8_t *in, size_t in_len)
 {
+    if ((in_len > STREAM_DEC_MIN || (in_len && getenv("LZS_FORCE_STREAM"))) && in_len <= LZS_BLOCK_MAX &&
+        out && in && out_cap && !getenv("LZS_ONE_WAVE")) {
+        const size_t got = stream_decompress(out, out_cap, in, in_len, 0, NULL, 1);
+        if (got != SIZE_MAX) return got;
+    }
     return one_shot("lzs_decompress_concat", lzs_hip_launch_decompress_concat, out, out_cap, in, in_len);
 }
 

@@ -2115,7 +2115,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                                                    uint32_t *exit_out, uint32_t *count_out,
                                                    uint8_t *out, uint32_t cap, uint32_t out_start,
                                                    uint32_t *origin_g, uint32_t *tainted_total,
-                                                   DecSegLds *Lp, uint32_t lane, uint32_t kDecSeg,
+                                                   DecSegLds *Lp, uint32_t lane, uint32_t kDecSeg, bool concat,
                                                    uint32_t *marks = nullptr, bool compare = false)
 {
     const uint32_t kDecEnd = 8u * kDecSeg;                        // the segment's length in bits
@@ -2251,7 +2251,12 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                 if (o == 0u) {
                     if (have < used) break;
                     bits <<= used; have -= used;
-                    if (is_short) break;                         // end marker: the stream ends here
+                    if (is_short) {
+                        if (!concat) break;                      // end marker: the stream ends here (:255-260)
+                        const uint32_t pad = have & 7u;          // file rule (:564-576): on from the next byte
+                        bits <<= pad; have -= pad;
+                        continue;
+                    }
                     off = 0;                                     // long offset 0: no copy (:280)
                     continue;
                 }
@@ -2324,7 +2329,7 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
                             const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
                             uint32_t *__restrict__ exit_state, uint32_t *__restrict__ count,
                             uint8_t *__restrict__ all_ones, uint32_t *__restrict__ marks, uint32_t compare,
-                            uint32_t kDecSeg)
+                            uint32_t kDecSeg, uint32_t concat)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * 4u + uniform(threadIdx.x >> 6);
@@ -2343,7 +2348,7 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
     }
     if (dirty && !dirty[k]) return;
     lzs_stream_segment<false>(in, n, k, uniform(entry[k]), exit_state + k, count + k,
-                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane, kDecSeg,
+                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane, kDecSeg, concat != 0u,
                               marks ? marks + (size_t)k * kScanMarkWords : nullptr, compare != 0u);
 }
 
@@ -2352,7 +2357,7 @@ void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t 
                               uint32_t *__restrict__ tainted_total,
                               const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
                               const uint32_t *__restrict__ entry, const uint32_t *__restrict__ out_start,
-                              uint32_t kDecSeg)
+                              uint32_t kDecSeg, uint32_t concat)
 {
     __shared__ DecSegLds lds[4];
     const uint32_t lane = threadIdx.x & 63u;
@@ -2362,7 +2367,7 @@ void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t 
     const uint32_t e = uniform(entry[k]);
     if (e & kSegStop) return;                                 // the stream ended before this segment
     lzs_stream_segment<true>(in, n, k, e, nullptr, nullptr, out, cap, uniform(out_start[k]),
-                             origin_g, tainted_total, &lds[wv], lane, kDecSeg);
+                             origin_g, tainted_total, &lds[wv], lane, kDecSeg, concat != 0u);
 }
 
 // One round of pointer jumping over the origins (each launch only trusts what earlier launches
@@ -2740,22 +2745,23 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
 
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
-                               uint8_t *d_all_ones, uint32_t *d_marks, int compare, uint32_t seg, void *stream)
+                               uint8_t *d_all_ones, uint32_t *d_marks, int compare, uint32_t seg, int concat,
+                               void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones,
-                       d_marks, compare ? 1u : 0u, seg);
+                       d_marks, compare ? 1u : 0u, seg, concat ? 1u : 0u);
     return (int)hipGetLastError();
 }
 
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
-                                 const uint32_t *d_out_start, uint32_t seg, void *stream)
+                                 const uint32_t *d_out_start, uint32_t seg, int concat, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg);
+                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u);
     return (int)hipGetLastError();
 }
 

@@ -493,6 +493,37 @@ def test_short_streams_decompressed_by_many_wavefronts_in_small_segments():
         assert lzs.decompress(ones, 30 * n + 100) == O.decompress(ones, 30 * n + 100)
 
 
+def test_concatenated_streams_decompressed_by_many_wavefronts():
+    """lzs_decompress_concat() (the file rule: go on after every end marker, history kept,
+    lzs-decompression.c:564-576) takes the many-wavefront route too from 4 KiB on.  Blocks
+    compressed one by one and laid end to end decode to the blocks laid end to end; on anything
+    else (cut capacity, truncated input, garbage with chance end markers in it) the result is the
+    one wavefront's (LZS_ONE_WAVE=1, the kernel the edge vectors pin)."""
+    import os
+    rng = np.random.default_rng(9)
+    blocks = [bytes(b) for cls in workload.CLASS_NAMES for b in workload.fill(cls, 12)]
+    blocks += [b"", b"a", bytes(100_000), blocks[0][:777]]
+    order = rng.permutation(len(blocks))
+    plain = b"".join(blocks[i] for i in order)
+    stream = b"".join(O.compress(blocks[i]) for i in order)
+    assert lzs.decompress_concat(stream, len(plain) + 9) == plain
+
+    def one_wave(data, cap):
+        os.environ["LZS_ONE_WAVE"] = "1"
+        try:
+            return lzs.decompress_concat(data, cap)
+        finally:
+            del os.environ["LZS_ONE_WAVE"]
+
+    small = stream[:300_000]
+    assert one_wave(small, 2_000_000) == lzs.decompress_concat(small, 2_000_000)
+    for cap in (1, 50_000, 123_457):
+        assert lzs.decompress_concat(small, cap) == one_wave(small, cap)
+    for _ in range(6):
+        junk = bytes(rng.integers(0, 256, int(rng.integers(4096, 60_000)), dtype=np.uint8))
+        assert lzs.decompress_concat(junk, 1_500_000) == one_wave(junk, 1_500_000)
+
+
 @pytest.mark.parametrize("variant", ["chain", "scan"])
 def test_other_kernel_variants_agree(variant):
     """The A/B variants (LZS_KERNEL=chain|scan) produce the same bytes as the default kernel."""
