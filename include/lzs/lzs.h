@@ -86,7 +86,8 @@ size_t lzs_decompress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_
  * encoded, bits of an unfinished token, output that did not fit) is kept in the
  * block itself -- nothing is allocated per stream, a block may be copied or dropped
  * at any time.  The streams produced and accepted are the reference's, bit for bit.
- * A call costs ~0.1 ms whatever its size: feed large pieces (MiB) for throughput;
+ * A call costs ~0.1 ms whatever its size: feed large pieces (MiB) for throughput
+ * (pieces of 16 KiB and more are spread over many wavefronts in both directions);
  * 512-byte pieces, the reference tools' habit, work and run at a few MB/s.
  * lzs_simple_compress_incremental (a low-RAM variant with the same output) is not
  * provided.  Without a HIP device: status = LZS_x_STATUS_ERROR, nothing consumed.

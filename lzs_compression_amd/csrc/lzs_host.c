@@ -553,9 +553,27 @@ static uint32_t stream_dec_seg(size_t n)
 /* lzs_decompress() of one long stream by many wavefronts: see lzs_scan_stream_kernel.  Returns
  * SIZE_MAX if this path does not apply (output of 4 GiB or more) and the caller should decode
  * with one wavefront. */
-static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, int concat)
+/* A piece of a stream for lzs_decompress_incremental(): the input is `prefix` (the bytes that hold
+ * the bits left over from the call before) followed by `in`; the walk starts in state `entry0`
+ * (bit offset into the first byte, extension running, offset: the kernels' state word); copies may
+ * reach back into `hist`, the last bytes produced before.  Only whole segments are decoded, and
+ * only those before the first one in which the stream stops (end marker, unfinished token) or
+ * which would overflow the output: the rest is the one wavefront's (lzs_decode_resume_kernel). */
+typedef struct {
+    const uint8_t *prefix;
+    uint32_t prefix_len;
+    uint32_t entry0;
+    const uint8_t *hist;
+    uint32_t hist_len;
+    /* results */
+    uint32_t seg, segs_done;    /* segment size used; segments decoded */
+    uint32_t next_entry;        /* state word at the start of segment segs_done */
+} dec_piece_t;
+
+static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, int concat,
+                                dec_piece_t *dp)
 {
-    const char *who = dev ? "lzs_decompress_stream_device" : concat ? "lzs_decompress_concat" : "lzs_decompress";
+    const char *who = dp ? "lzs_decompress_incremental" : dev ? "lzs_decompress_stream_device" : concat ? "lzs_decompress_concat" : "lzs_decompress";
     const uint32_t seg = stream_dec_seg(n);
     const uint32_t nseg = (uint32_t)((n + seg - 1) / seg);
     size_t result = 0;
@@ -595,9 +613,14 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
 
     const int debug = getenv("LZS_STREAM_DEBUG") != NULL;
     double t0 = debug ? now_ms() : 0, t1;
-    if (!dev) HIP_TRY(lzs_hip_h2d(d_in, in, n, stream), "hipMemcpy H2D");
+    if (!dev) {
+        const size_t pre = dp ? dp->prefix_len : 0;
+        if (pre) HIP_TRY(lzs_hip_h2d(d_in, dp->prefix, pre, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + pre, in, n - pre, stream), "hipMemcpy H2D");
+    }
     /* SCAN rounds: every segment entered at its first bit in the normal state, then corrected */
     for (uint32_t k = 0; k < nseg; k++) { entry[k] = 0; dirty[k] = 1; seen[k] = 0xFFFFFFFFu; }
+    if (dp) entry[0] = dp->entry0;
     for (uint32_t round = 0, ndirty = nseg; ndirty; round++) {
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
@@ -646,22 +669,30 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: round %u scanned %u of %u segments in %.2f ms; %u to redo\n", round, was, nseg, t1 - t0, ndirty); t0 = t1; }
     }
     uint64_t total = 0;
+    uint32_t ndec = nseg;                                      /* segments to decode */
+    const uint32_t before = dp ? dp->hist_len : 0;             /* bytes in front of out[0] that copies may reach */
     for (uint32_t k = 0; k < nseg; k++) {
-        start[k] = (uint32_t)total;
+        if (dp && ((exits[k] & LZS_SEG_STOP) || (entry[k] & LZS_SEG_STOP) || total + count[k] > cap)) { ndec = k; break; }
+        start[k] = (uint32_t)total + before;
         if (!(entry[k] & LZS_SEG_STOP)) total += count[k];
         if (total >= 0xFFFFFF00ull - 0x100000ull) break;
     }
     if (total >= 0xFFFFFF00ull - 0x100000ull) { result = SIZE_MAX; goto done; }   /* positions are 32-bit here */
+    if (dp) { dp->seg = seg; dp->segs_done = ndec; dp->next_entry = ndec < nseg ? entry[ndec] : exits[nseg - 1]; }
     const uint32_t produce = (uint32_t)(total < cap ? total : cap);
     if (produce) {
-        if (dev) d_out = out; else e = staging_reserve(st, BUF_OUT, (size_t)produce + 64, &d_out);
-        if (!e) e = staging_reserve(st, BUF_KEEP, 4 * (size_t)produce + 64, &d_origin);
+        if (dev) d_out = out; else e = staging_reserve(st, BUF_OUT, (size_t)before + produce + 64, &d_out);
+        if (!e) e = staging_reserve(st, BUF_KEEP, 4 * ((size_t)before + produce) + 64, &d_origin);
         if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+        if (before) {                                          /* the history: final bytes (origin "clean" = all ones) */
+            HIP_TRY(lzs_hip_h2d(d_out, dp->hist, before, stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_memset(d_origin, 0xFF, 4 * (size_t)before, stream), "hipMemset");
+        }
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
-        HIP_TRY(lzs_hip_launch_decode_stream(d_out, produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
-                                             nseg, d_entry, d_start, seg, concat, stream), who);
+        HIP_TRY(lzs_hip_launch_decode_stream(d_out, before + produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
+                                             ndec, d_entry, d_start, seg, concat, stream), who);
         uint32_t open[2] = {0, 0};
         HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -669,13 +700,13 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         uint32_t left = open[0];
         for (uint32_t round = 1; left && round < 250; round++) {
             HIP_TRY(lzs_hip_memset(d_counters + 1, 0, 4, stream), "hipMemset");
-            HIP_TRY(lzs_hip_launch_resolve_stream(d_out, (uint32_t *)d_origin, produce, round, d_counters + 1, stream), who);
+            HIP_TRY(lzs_hip_launch_resolve_stream(d_out, (uint32_t *)d_origin, before + produce, round, d_counters + 1, stream), who);
             HIP_TRY(lzs_hip_d2h(&left, d_counters + 1, 4, stream), "hipMemcpy D2H");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
             if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: resolve round %u in %.2f ms, %u left\n", round, t1 - t0, left); t0 = t1; }
         }
         if (left) { fail(LZS_E_HIP, "%s: origins did not resolve", who); goto failed; }
-        if (!dev) HIP_TRY(lzs_hip_d2h(out, d_out, produce, stream), "hipMemcpy D2H");
+        if (!dev) HIP_TRY(lzs_hip_d2h(out, (uint8_t *)d_out + before, produce, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
     }
     result = produce;
@@ -702,7 +733,7 @@ int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len, c
     if (in_len == 0 || out_cap == 0) return LZS_OK;
     if (in_len > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "lzs_decompress_stream_device: stream exceeds LZS_BLOCK_MAX");
     int rc = LZS_OK;
-    const size_t got = stream_decompress((uint8_t *)d_out, out_cap, (const uint8_t *)d_in, in_len, 1, &rc, 0);
+    const size_t got = stream_decompress((uint8_t *)d_out, out_cap, (const uint8_t *)d_in, in_len, 1, &rc, 0, NULL);
     if (got == SIZE_MAX) return fail(LZS_E_ARG, "lzs_decompress_stream_device: output of 4 GiB or more");
     *out_len = got;
     return rc;
@@ -712,7 +743,7 @@ size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t
 {
     if ((a_inLen > STREAM_DEC_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX &&
         a_pOutData && a_pInData && a_outBufferSize && !getenv("LZS_ONE_WAVE")) {
-        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL, 0);
+        const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL, 0, NULL);
         if (got != SIZE_MAX) return got;
     }
     return one_shot("lzs_decompress", lzs_hip_launch_decompress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
@@ -722,7 +753,7 @@ size_t lzs_decompress_concat(uint8_t *out, size_t out_cap, const uint8_t *in, si
 {
     if ((in_len > STREAM_DEC_MIN || (in_len && getenv("LZS_FORCE_STREAM"))) && in_len <= LZS_BLOCK_MAX &&
         out && in && out_cap && !getenv("LZS_ONE_WAVE")) {
-        const size_t got = stream_decompress(out, out_cap, in, in_len, 0, NULL, 1);
+        const size_t got = stream_decompress(out, out_cap, in, in_len, 0, NULL, 1, NULL);
         if (got != SIZE_MAX) return got;
     }
     return one_shot("lzs_decompress_concat", lzs_hip_launch_decompress_concat, out, out_cap, in, in_len);
@@ -741,6 +772,7 @@ typedef struct __attribute__((packed)) {
 } dec_priv_t;
 #define DEC_PRIV_AT 36u
 #define DEC_SMALL     16384u        /* calls up to this much input and output take the short way */
+#define INC_DEC_STREAM_MIN 16384u   /* pieces from this size on go to many wavefronts first */
 #define DEC_STATE_PAD 2112u         /* sizeof(lzs_dec_resume_t) rounded up to 64 */
 #define INC_BOX_BYTES (2 * (size_t)DEC_SMALL + DEC_STATE_PAD + 64)
 _Static_assert(sizeof(lzs_dec_resume_t) <= DEC_STATE_PAD, "state fits its slot");
@@ -783,10 +815,60 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     void *stream = st->stream;
     lzs_dec_resume_t h;
     memset(&h, 0, sizeof(h));
+    size_t wave_limit = (size_t)16 << 20;
     for (;;) {
+        /* A large piece first goes to many wavefronts (stream_decompress) as far as
+         * whole segments can be decoded; what is left -- the segment with the end marker, the
+         * unfinished token at the end of the input, the last bytes before the output is full, a
+         * copy still running -- is the one wavefront's below. */
+        if (pv->rem == 0 && p->inLength >= INC_DEC_STREAM_MIN && p->outLength >= 4096u && !getenv("LZS_ONE_WAVE")) {
+            const size_t big = p->inLength < ((size_t)256 << 20) ? p->inLength : ((size_t)256 << 20);
+            const uint32_t nb = (pv->qlen + 7u) / 8u;
+            uint8_t pre[4] = {0, 0, 0, 0};
+            const uint32_t v = pv->qlen ? pv->bitq >> (32u - pv->qlen) : 0u;     /* the queued bits, right-aligned */
+            for (uint32_t i = 0; i < nb; i++) pre[i] = (uint8_t)(v >> (8u * (nb - 1u - i)));
+            dec_piece_t dp;
+            memset(&dp, 0, sizeof(dp));
+            dp.prefix = pre; dp.prefix_len = nb;
+            dp.entry0 = (8u * nb - pv->qlen) | ((uint32_t)(pv->extended != 0) << 8) | ((pv->extended ? (uint32_t)pv->off : 0u) << 9);
+            dp.hist = pv->hist; dp.hist_len = pv->hist_len;
+            const size_t room = p->outLength < 0xE0000000u ? p->outLength : 0xE0000000u;
+            int rc = LZS_OK;
+            const size_t got = stream_decompress(p->outPtr, room, p->inPtr, nb + big, 0, &rc, 0, &dp);
+            if (rc != LZS_OK) { p->status = LZS_D_STATUS_ERROR; return made; }
+            if (got != SIZE_MAX && dp.segs_done > 0) {
+                const size_t at = (size_t)dp.segs_done * dp.seg + ((dp.next_entry & 0xFFu) >> 3);   /* in prefix + input */
+                const uint32_t b = dp.next_entry & 7u;
+                if (at < nb || at - nb + (b ? 1u : 0u) > big || (dp.next_entry & LZS_SEG_STOP) || got > room) {
+                    fail(LZS_E_HIP, "%s: inconsistent state from the device", who);
+                    goto failed;
+                }
+                pv->qlen = b ? (uint8_t)(8u - b) : 0;
+                pv->bitq = b ? (uint32_t)p->inPtr[at - nb] << (24u + b) : 0u;
+                pv->extended = (uint8_t)((dp.next_entry >> 8) & 1u);
+                if (pv->extended) pv->off = (uint16_t)((dp.next_entry >> 9) & 0x7FFu);
+                /* the history: the last 2047 bytes of what was there and what came now */
+                if (got >= LZS_MAX_HISTORY_SIZE) {
+                    memcpy(pv->hist, p->outPtr + got - LZS_MAX_HISTORY_SIZE, LZS_MAX_HISTORY_SIZE);
+                    pv->hist_len = LZS_MAX_HISTORY_SIZE;
+                } else {
+                    const size_t keep = (size_t)pv->hist_len + got > LZS_MAX_HISTORY_SIZE ? LZS_MAX_HISTORY_SIZE - got : pv->hist_len;
+                    memmove(pv->hist, pv->hist + pv->hist_len - keep, keep);
+                    memcpy(pv->hist + keep, p->outPtr, got);
+                    pv->hist_len = (uint16_t)(keep + got);
+                }
+                const size_t used = at - nb + (b ? 1u : 0u);
+                p->inPtr += used;  p->inLength -= used;
+                p->outPtr += got;  p->outLength -= got;
+                made += got;
+                if (p->inLength == 0 && pv->qlen == 0) { p->status = LZS_D_STATUS_INPUT_FINISHED | LZS_D_STATUS_INPUT_STARVED; break; }
+            }
+            /* not even one whole segment this time: the wavefront takes the next stretch */
+            wave_limit = 4u * (size_t)(dp.seg ? dp.seg : 8192u);
+        }
         /* one launch takes at most 16 MiB of input; its output is bounded by 30x that
          * (a length nibble stands for 15 bytes) */
-        const size_t take = p->inLength < ((size_t)16 << 20) ? p->inLength : ((size_t)16 << 20);
+        const size_t take = p->inLength < wave_limit ? p->inLength : wave_limit;
         const size_t most = 30u * (take + 4u) + 64u;
         const size_t cap = p->outLength < most ? p->outLength : most;
         void *d_in = NULL, *d_out = NULL, *d_state = NULL;

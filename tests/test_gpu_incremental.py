@@ -228,3 +228,19 @@ def test_garbage_decodes_like_the_reference_incremental_decoder():
         for ins, outs in ((_const(len(stream)), _const(4096)), (_rand(rng, 1, 9), _rand(rng, 1, 50))):
             got, markers = _decode(stream, ins, outs)
             assert got == want and markers == v["markers"], v["in"]
+
+
+def test_large_pieces_decode_through_many_wavefronts():
+    """Pieces of 16 KiB and more are decoded by many wavefronts as far as whole segments go
+    (history, the bits left over from the call before and a running extension carried in), the
+    rest by the one wavefront: several streams back to back (end markers in the middle of pieces),
+    long runs, output space smaller and larger than what a piece produces."""
+    rng = random.Random(41)
+    t = _sample("text", 900000)
+    plains = [t[:400000], bytes(300000) + t[400000:500000] + b"q" * 200000, _sample("random", 150000), t[500000:900000]]
+    stream = b"".join(O.compress(x) for x in plains)
+    want = b"".join(plains)
+    for (ilo, ihi), (olo, ohi) in (((16384, 16384), (1 << 20, 1 << 20)), ((20000, 300000), (5000, 400000)),
+                                   ((len(stream), len(stream)), (4096, 100000)), ((100000, 100000), (1 << 22, 1 << 22))):
+        got, markers = _decode(stream, _rand(rng, ilo, ihi), _rand(rng, olo, ohi))
+        assert got == want and markers == len(plains), (ilo, ihi, olo, ohi, len(got), markers)
