@@ -212,6 +212,7 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     const size_t d_in_stride = round_up(in_len ? in_len : 1, 16);
     const size_t d_out_stride = round_up(cap32 ? cap32 : 1, 16);
     void *stream = NULL, *d_in = NULL, *d_out = NULL, *d_len = NULL, *d_in_len = NULL;
+    uint8_t *bounce[2] = {NULL, NULL};
     int e = 0;
     rc = LZS_OK;
     staging_t *st = staging_get();
@@ -228,12 +229,27 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
 
     if (in_stride == d_in_stride && !in_len_each) {
         HIP_TRY(lzs_hip_h2d(d_in, in, d_in_stride * (nblocks - 1) + in_len, stream), "hipMemcpy H2D");
-    } else {
+    } else if (nblocks < 16) {
         for (size_t b = 0; b < nblocks; b++) {
             size_t len_b = in_len_each ? in_len_each[b] : in_len;
             HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + b * d_in_stride, in + b * in_stride, len_b, stream),
                     "hipMemcpy H2D");
         }
+    } else {
+        /* ragged or strided blocks: laid out at the device stride by the CPU, 32 MiB at a time
+         * (thousands of small copies cost more than the data) */
+        size_t per = ((size_t)32 << 20) / d_in_stride;
+        if (per == 0) per = 1;
+        bounce[0] = (uint8_t *)malloc(per * d_in_stride);
+        if (!bounce[0]) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+        for (size_t b0 = 0; b0 < nblocks; b0 += per) {
+            const size_t nb = nblocks - b0 < per ? nblocks - b0 : per;
+            for (size_t b = 0; b < nb; b++)
+                memcpy(bounce[0] + b * d_in_stride, in + (b0 + b) * in_stride, in_len_each ? in_len_each[b0 + b] : in_len);
+            HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + b0 * d_in_stride, bounce[0], nb * d_in_stride, stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        }
+        free(bounce[0]); bounce[0] = NULL;
     }
     if (in_len_each)
         HIP_TRY(lzs_hip_h2d(d_in_len, in_len_each, sizeof(uint32_t) * nblocks, stream), "hipMemcpy H2D");
@@ -243,14 +259,54 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     HIP_TRY(lzs_hip_d2h(out_len, d_len, sizeof(uint32_t) * nblocks, stream), "hipMemcpy D2H");
     HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
     /* copy back only what each block produced: nothing past out_len[b] is touched */
-    for (size_t b = 0; b < nblocks; b++)
-        HIP_TRY(lzs_hip_d2h(out + b * out_stride, (uint8_t *)d_out + b * d_out_stride, out_len[b], stream),
-                "hipMemcpy D2H");
-    HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    if (nblocks < 16) {
+        for (size_t b = 0; b < nblocks; b++)
+            HIP_TRY(lzs_hip_d2h(out + b * out_stride, (uint8_t *)d_out + b * d_out_stride, out_len[b], stream),
+                    "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    } else {
+        /* Thousands of small copies cost more than the data: the results are gathered into one
+         * dense string on the device, come back in pieces of 32 MiB, and are laid out by the CPU.
+         * (Full blocks at the device's own stride need neither: one copy.) */
+        size_t total = 0, full = 0;
+        for (size_t b = 0; b < nblocks; b++) { total += out_len[b]; full += (b + 1 < nblocks) && out_len[b] == out_stride; }
+        if (out_stride == d_out_stride && full == nblocks - 1) {
+            HIP_TRY(lzs_hip_d2h(out, d_out, total, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+            goto done;
+        }
+        void *d_dense = NULL, *d_offs = NULL;
+        e = staging_reserve(st, BUF_KEEP, total + 64, &d_dense);
+        if (!e) e = staging_reserve(st, BUF_AUX, sizeof(uint64_t) * (nblocks + 1), &d_offs);
+        if (e) { rc = fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
+        HIP_TRY(lzs_hip_launch_compact(d_dense, (uint64_t *)d_offs, d_out, d_out_stride, (const uint32_t *)d_len,
+                                       (uint32_t)nblocks, stream), who);
+        const size_t piece = (size_t)32 << 20;
+        bounce[0] = (uint8_t *)malloc(total < piece ? total + 1 : piece);
+        bounce[1] = total > piece ? (uint8_t *)malloc(piece) : NULL;
+        if (!bounce[0] || (total > piece && !bounce[1])) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+        size_t b = 0, within = 0;                              /* next block to lay out, bytes of it already done */
+        for (size_t at = 0, k = 0; at < total || k == 0; k++) {
+            const size_t len = total - at < piece ? total - at : piece;
+            HIP_TRY(lzs_hip_d2h(bounce[k & 1], (uint8_t *)d_dense + at, len, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+            const uint8_t *src = bounce[k & 1];
+            size_t left = len;
+            while (left) {
+                while (b < nblocks && within == out_len[b]) { b++; within = 0; }
+                const size_t m = out_len[b] - within < left ? out_len[b] - within : left;
+                memcpy(out + b * out_stride + within, src, m);
+                src += m; left -= m; within += m;
+            }
+            at += len;
+            if (len == 0) break;
+        }
+    }
 #undef HIP_TRY
 
 done:
     if (rc != LZS_OK && stream) lzs_hip_stream_sync(stream);   /* nothing of ours may still be in flight */
+    free(bounce[0]); free(bounce[1]);
     staging_trim(st);
     return rc;
 }
