@@ -681,7 +681,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0, seg, concat, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !getenv("LZS_NO_MARKS"), seg, concat, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
@@ -706,11 +706,16 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
             /* a segment behind the (current) end of the stream keeps what it reported for its last
              * entry: the end may turn out to be a misread of a walk that had not fallen in step */
             if (ended || want == seen[k]) continue;
-            if (((want >> 8) & 1u) && ones[k]) {
-                /* all 0xFF inside a running extension: 65536 nibbles of 15, leaves as it was entered
-                 * (the segment length in bits is a multiple of 4); no need to walk it */
-                exits[k] = want;
-                count[k] = 15u * (seg * 8u / 4u);
+            if (((want >> 8) & 1u) && (ones[k] == 2 || (ones[k] && (want & 3u) == 0)) && !getenv("LZS_NO_ONES")) {
+                /* all 0xFF inside a running extension: nothing but nibbles of 15, one every 4 bits
+                 * from the cursor on (which is up to 20 bits in if the match token itself straddles
+                 * the border) for as long as they start inside the segment -- provided the last of
+                 * them is all ones too, which reaches up to 3 bits into the next segment unless the
+                 * cursor is a multiple of 4.  No need to walk it then. */
+                const uint32_t r = want & 0xFFu;
+                const uint32_t nibbles = (seg * 8u - r + 3u) / 4u;
+                exits[k] = (want & ~0xFFu) | (r + 4u * nibbles - seg * 8u);
+                count[k] = 15u * nibbles;
                 seen[k] = want;
                 continue;
             }
@@ -723,6 +728,25 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
             HIP_TRY(lzs_hip_h2d(d_count, count, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         }
         if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: round %u scanned %u of %u segments in %.2f ms; %u to redo\n", round, was, nseg, t1 - t0, ndirty); t0 = t1; }
+    }
+    if (getenv("LZS_VERIFY_SCAN")) {
+        /* development check: every segment walked in full from its final entry must report what
+         * the rounds arrived at (merged walks and the all-0xFF shortcut included) */
+        uint32_t *ex2 = (uint32_t *)malloc(sizeof(uint32_t) * nseg), *cn2 = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+        memset(dirty, 1, nseg);
+        HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count, NULL, NULL, 0, seg, concat, stream), who);
+        HIP_TRY(lzs_hip_d2h(ex2, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_d2h(cn2, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        for (uint32_t k = 0; k < nseg; k++) {
+            if (entry[k] & LZS_SEG_STOP) break;
+            if (ex2[k] != exits[k] || cn2[k] != count[k])
+                fprintf(stderr, "liblzs verify: segment %u entry %08x: rounds say exit %08x count %u, a full walk says %08x %u (all-ones %u)\n",
+                        k, entry[k], exits[k], count[k], ex2[k], cn2[k], ones[k]);
+        }
+        free(ex2); free(cn2);
     }
     uint64_t total = 0;
     uint32_t ndec = nseg;                                      /* segments to decode */

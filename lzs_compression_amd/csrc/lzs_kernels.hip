@@ -2344,7 +2344,10 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
             for (uint32_t i = lane; i < kDecSeg && ones; i += 64u) ones = p[i] == 0xFFu;
         }
         const bool all = __builtin_amdgcn_ballot_w64(!ones) == 0ull;
-        if (lane == 0) all_ones[k] = all;
+        // 2: and so are the first three bits after it (the last nibble that starts in the segment
+        // may reach that far into the next one)
+        const size_t after = (size_t)(k + 1u) * kDecSeg;
+        if (lane == 0) all_ones[k] = !all ? 0 : (after < n && (in[after] & 0xE0u) == 0xE0u) ? 2 : 1;
     }
     if (dirty && !dirty[k]) return;
     lzs_stream_segment<false>(in, n, k, uniform(entry[k]), exit_state + k, count + k,

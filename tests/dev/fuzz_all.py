@@ -1,0 +1,138 @@
+"""Dev aid: randomized cross-check of every host-visible path against the oracle for a given number
+of seconds (argv[1], default 300).  Prints the seed of any failure."""
+import os, sys, time, random
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+import numpy as np
+import oracle
+import lzs_compression_amd as lzs
+from lzs_compression_amd import api, workload
+
+O = oracle.oracle()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+TRACE = os.environ.get("FUZZ_TRACE")
+
+
+def stage(seed, name, **kw):
+    if TRACE:
+        print("stage", seed, name, kw, {k: os.environ.get(k) for k in ("LZS_STREAM_SEG", "LZS_DEC_SEG", "LZS_FORCE_STREAM")}, flush=True)
+
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+text = bytes(workload.fill("text", 16).reshape(-1))
+low = bytes(workload.fill("lowent", 16).reshape(-1))
+
+
+def make(rng, maxlen):
+    out = bytearray()
+    target = rng.randint(0, maxlen)
+    while len(out) < target:
+        k = rng.randint(0, 6)
+        if k == 0:
+            out += bytes([rng.randint(0, 255)]) * rng.randint(1, 40000)
+        elif k == 1:
+            a = rng.randint(0, len(text) - 2); out += text[a:a + rng.randint(1, 60000)]
+        elif k == 2:
+            out += rng.randbytes(rng.randint(1, 20000))
+        elif k == 3:
+            unit = rng.randbytes(rng.randint(1, 3000)); out += unit * rng.randint(1, 40)
+        elif k == 4:
+            a = rng.randint(0, len(low) - 2); out += low[a:a + rng.randint(1, 100000)]
+        elif k == 5 and len(out) > 10:
+            a = rng.randint(0, len(out) - 1); out += out[a:a + rng.randint(1, 5000)]      # far or near repeat
+        else:
+            out += bytes(rng.choice(b"ab") for _ in range(rng.randint(1, 300)))
+    return bytes(out[:target])
+
+
+def pieces(rng, lo, hi):
+    while True:
+        yield rng.randint(lo, hi)
+
+
+def inc_encode(rng, data):
+    c = lzs.IncrementalCompressor()
+    lo, hi = rng.choice(((1, 50), (100, 5000), (5000, 300000)))
+    out, pos, pending, fin, status = bytearray(), 0, b"", False, 0
+    for _ in range(10 ** 7):
+        if not pending and not fin and pos < len(data):
+            pending = data[pos:pos + rng.randint(lo, hi)]; pos += len(pending)
+        if not pending and pos >= len(data) and (status & 1 or not data):
+            fin = True
+        got, used, status = c.step(pending, rng.randint(max(lo, 3), hi), fin)
+        out += got; pending = pending[used:]
+        if status & 4:
+            return bytes(out)
+    raise RuntimeError("no progress")
+
+
+def inc_decode(rng, stream):
+    d = lzs.IncrementalDecompressor()
+    lo, hi = rng.choice(((1, 50), (100, 5000), (5000, 300000)))
+    out, pos, pending = bytearray(), 0, b""
+    for _ in range(10 ** 7):
+        if not pending and pos < len(stream):
+            pending = stream[pos:pos + rng.randint(lo, hi)]; pos += len(pending)
+        got, used, status = d.step(pending, rng.randint(lo, 3 * hi))
+        out += got; pending = pending[used:]
+        if status & 4 or (not pending and pos >= len(stream) and status & 1):
+            return bytes(out)
+    raise RuntimeError("no progress")
+
+
+t0, it = time.time(), 0
+ONLY = os.environ.get("FUZZ_ONLY")
+while time.time() - t0 < budget:
+    seed = int(ONLY) if ONLY else seed0 * 100000 + it
+    if ONLY and it:
+        break
+    rng = random.Random(seed)
+    it += 1
+    try:
+        d = make(rng, rng.choice((3000, 60000, 400000, 1500000)))
+        want = O.compress(d)
+        for k in ("LZS_STREAM_SEG", "LZS_DEC_SEG", "LZS_FORCE_STREAM"):
+            os.environ.pop(k, None)
+        if rng.random() < 0.6:
+            os.environ["LZS_STREAM_SEG"] = str(rng.choice((4096, 8192, 16384, 65536)))
+        if rng.random() < 0.6:
+            os.environ["LZS_DEC_SEG"] = str(rng.choice((256, 512, 1024, 2048, 8192)))
+        if rng.random() < 0.3:
+            os.environ["LZS_FORCE_STREAM"] = "1"
+        stage(seed, "compress", n=len(d))
+        assert lzs.compress(d) == want, "compress"
+        cap = rng.choice((len(d) + 7, len(d), max(len(d) - 1, 0), len(d) // 2, 1))
+        if cap:
+            stage(seed, "decompress", n=len(want), cap=cap)
+            assert lzs.decompress(want, cap) == d[:cap], "decompress"
+            cut = rng.randint(0, len(want))
+            stage(seed, "decompress cut", cut=cut)
+            assert lzs.decompress(want[:cut], len(d) + 1) == O.decompress(want[:cut], len(d) + 1), "decompress cut"
+        junk = rng.randbytes(rng.randint(1, 30000))
+        stage(seed, "junk", n=len(junk))
+        assert lzs.decompress(junk, 500000) == O.decompress(junk, 500000), "decompress junk"
+        small = d[:rng.randint(0, min(len(d), 300000))]
+        stage(seed, "inc encode", n=len(small))
+        assert inc_encode(rng, small) == O.compress(small), "incremental encode"
+        stage(seed, "inc decode", n=len(want))
+        assert inc_decode(rng, want) == d, "incremental decode"
+        stage(seed, "batch")
+        nb = rng.randint(1, 40)
+        blocks = [make(rng, 70000) for _ in range(nb)]
+        stride = max(1, max(len(b) for b in blocks))
+        arr = np.zeros((nb, stride), dtype=np.uint8); lens = np.zeros(nb, dtype=np.uint32)
+        for i, b in enumerate(blocks):
+            arr[i, :len(b)] = np.frombuffer(b, dtype=np.uint8); lens[i] = len(b)
+        out, n = lzs.compress_batch(arr, lens)
+        for i, b in enumerate(blocks):
+            assert out[i, :n[i]].tobytes() == O.compress(b), "compress_batch"
+        back, m = lzs.decompress_batch(out, n, stride)
+        for i, b in enumerate(blocks):
+            assert back[i, :m[i]].tobytes() == b, "decompress_batch"
+    except Exception as e:
+        import pickle
+        os.makedirs(os.path.join(os.path.dirname(__file__), "..", "..", "gpurun_out"), exist_ok=True)
+        keep = {k: v for k, v in locals().items() if k in ("d", "want", "cap", "cut", "junk", "small", "blocks", "seed")}
+        keep["env"] = {k: os.environ.get(k) for k in ("LZS_STREAM_SEG", "LZS_DEC_SEG", "LZS_FORCE_STREAM")}
+        pickle.dump(keep, open(os.path.join(os.path.dirname(__file__), "..", "..", "gpurun_out", "fuzz_fail_%d.pkl" % seed), "wb"))
+        print("FAIL seed", seed, repr(e)[:300], {k: os.environ.get(k) for k in ("LZS_STREAM_SEG", "LZS_DEC_SEG", "LZS_FORCE_STREAM")}, flush=True)
+        raise
+print(f"fuzz ok: {it} iterations in {time.time() - t0:.0f} s")

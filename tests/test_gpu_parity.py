@@ -493,6 +493,29 @@ def test_short_streams_decompressed_by_many_wavefronts_in_small_segments():
         assert lzs.decompress(ones, 30 * n + 100) == O.decompress(ones, 30 * n + 100)
 
 
+def test_long_match_ending_at_a_segment_border_of_all_ones():
+    """A long run is thousands of 1111 nibbles; a segment that is nothing but 0xFF inside a running
+    extension is not walked, its exit is worked out by the host -- which is only right if the last
+    nibble that starts in it is 1111 as well, and that one reaches up to 3 bits into the next
+    segment.  Runs of every length modulo a segment's worth, at every bit phase, in the smallest
+    segments (found by tests/dev/fuzz_all.py: seeds 100067, 100358)."""
+    import os
+    os.environ["LZS_DEC_SEG"] = "256"
+    try:
+        bad = 0
+        for phase in range(4):
+            head = b"abc"[:phase] + b"\x00"
+            for run in range(9000, 9000 + 7700, 7):
+                d = head + b"\x90" * run + b"tail of the block"
+                comp = O.compress(d)
+                assert len(comp) >= 256
+                os.environ["LZS_FORCE_STREAM"] = "1"
+                bad += lzs.decompress(comp, len(d) + 3) != d
+        assert bad == 0
+    finally:
+        os.environ.pop("LZS_DEC_SEG", None); os.environ.pop("LZS_FORCE_STREAM", None)
+
+
 def test_concatenated_streams_decompressed_by_many_wavefronts():
     """lzs_decompress_concat() (the file rule: go on after every end marker, history kept,
     lzs-decompression.c:564-576) takes the many-wavefront route too from 4 KiB on.  Blocks
