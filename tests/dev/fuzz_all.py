@@ -114,6 +114,13 @@ while time.time() - t0 < budget:
         assert inc_encode(rng, small) == O.compress(small), "incremental encode"
         stage(seed, "inc decode", n=len(want))
         assert inc_decode(rng, want) == d, "incremental decode"
+        ccap = rng.randint(0, len(want) + 3)
+        stage(seed, "compress cap", ccap=ccap)
+        assert lzs.compress(d, ccap) == want[:ccap], "compress with a cut capacity"
+        parts = [make(rng, 50000) for _ in range(rng.randint(1, 6))]
+        cat = b"".join(O.compress(x) for x in parts)
+        stage(seed, "concat", n=len(cat))
+        assert lzs.decompress_concat(cat, sum(map(len, parts)) + 5) == b"".join(parts), "decompress_concat"
         stage(seed, "batch")
         nb = rng.randint(1, 40)
         blocks = [make(rng, 70000) for _ in range(nb)]
