@@ -60,17 +60,26 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
 int lzs_hip_launch_extend_resume(void *d_out, uint32_t bit0, const void *d_in, uint32_t n, uint32_t c0,
                                  uint32_t off, int last, uint32_t *d_result, void *stream);
 /* One long stream decompressed by many wavefronts (lzs_scan_stream_kernel, lzs_decode_stream_kernel,
- * lzs_resolve_stream_kernel; state words and the scheme are described at the kernels). */
+ * lzs_resolve_stream_kernel; state words and the scheme are described at the kernels).  With the
+ * tables (all NULL for one stream) the segments belong to many streams in one buffer -- a batch of
+ * blocks: segment k starts at d_in[d_seg_base[k]], its stream ends at d_in[d_seg_end[k]], copies
+ * reaching before d_out[d_out_floor[k]] yield zeros and nothing is written at or past
+ * d_out[d_out_limit[k]]. */
 #define LZS_SEG_STOP (1u << 30)
 unsigned lzs_hip_dec_segment_bytes(void);             /* the largest segment (long streams) */
 #define LZS_SCAN_MARK_WORDS 132u     /* per segment in d_marks: what a full walk leaves for repeated ones */
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones /* or NULL */, uint32_t *d_marks, int compare,
-                               uint32_t seg, int concat /* go on after end markers */, void *stream);
+                               uint32_t seg, int concat /* go on after end markers */,
+                               const uint32_t *d_seg_base, const uint32_t *d_seg_end /* or NULL, NULL */, void *stream);
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
-                                 const uint32_t *d_out_start, uint32_t seg, int concat, void *stream);
+                                 const uint32_t *d_out_start, uint32_t seg, int concat,
+                                 const uint32_t *d_seg_base, const uint32_t *d_seg_end,
+                                 const uint32_t *d_out_floor, const uint32_t *d_out_limit, void *stream);
+int lzs_hip_launch_resolve_blocks(void *d_out, uint32_t *d_origin, size_t out_stride, const uint32_t *d_len,
+                                  uint32_t nblocks, void *stream);   /* a batch: one workgroup per block, to the end */
 int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
                                   uint32_t *d_left, void *stream);
 /* The incremental entry points (lzs_incremental.c).  Status bits as in the reference's

@@ -118,6 +118,13 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
  * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
 enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_MARKS, BUF_COUNT };
 #define KEEP_MAX ((size_t)256 << 20)
+#define STREAM_DEC_MIN 4096u                                /* shorter streams are decompressed by one wavefront */
+/* Batches up to this much output are decompressed in segments; larger ones fill the device with a
+ * wavefront per block.  Measured (text, 64 KiB blocks, host buffers, ms; segments / wavefront per
+ * block): 4 blocks 0.74 / 8.3, 64 blocks 1.5 / 8.5, 256 blocks 4.2 / 9.4, 512 blocks 11.4 / 13.4,
+ * 1024 blocks 25.5 / 24.8. */
+#define BATCH_SEG_MAX_BLOCKS 4096u
+#define BATCH_SEG_MAX_EXTENT ((unsigned long long)32 << 20)
 
 typedef struct {
     void  *stream;
@@ -187,6 +194,13 @@ static void staging_trim(staging_t *st)
 }
 
 /* -------------------------------------------------------------------- host batches */
+static uint32_t stream_dec_seg(size_t n);
+static double now_ms(void);
+static int batch_decompress_segments(staging_t *st, void *stream, const char *who, void *d_out, size_t d_out_stride,
+                                     uint32_t cap32, uint32_t *out_len, uint32_t *d_len, const void *d_in, size_t d_in_stride,
+                                     const uint32_t *in_len_each, uint32_t in_len, size_t nblocks);
+int lzs_hip_launch_decompress(void *, size_t, uint32_t, uint32_t *, const void *, size_t, const uint32_t *, uint32_t, uint32_t, void *);
+
 /* Stage host buffers through this thread's device memory.  Blocks are packed on the device
  * with 16-byte-aligned strides so the kernels take their aligned paths, whatever the
  * caller's strides are. */
@@ -254,10 +268,27 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     if (in_len_each)
         HIP_TRY(lzs_hip_h2d(d_in_len, in_len_each, sizeof(uint32_t) * nblocks, stream), "hipMemcpy H2D");
 
-    HIP_TRY(launch(d_out, d_out_stride, cap32, (uint32_t *)d_len, d_in, d_in_stride,
-                   (const uint32_t *)d_in_len, (uint32_t)in_len, (uint32_t)nblocks, stream), who);
-    HIP_TRY(lzs_hip_d2h(out_len, d_len, sizeof(uint32_t) * nblocks, stream), "hipMemcpy D2H");
-    HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    /* A small batch of blocks to decompress does not fill the device with one wavefront per block
+     * (a wavefront takes 9 ms for a 64 KiB block, whatever the batch): then the blocks are cut
+     * into segments for many wavefronts, like one long stream. */
+    int segmented = 0;
+    if (launch == lzs_hip_launch_decompress && cap32 && !getenv("LZS_ONE_WAVE")) {
+        size_t total_in = 0;
+        for (size_t b = 0; b < nblocks; b++) total_in += in_len_each ? in_len_each[b] : in_len;
+        if (nblocks <= BATCH_SEG_MAX_BLOCKS && total_in >= STREAM_DEC_MIN && total_in / nblocks >= 1024u &&
+            (unsigned long long)nblocks * d_out_stride <= BATCH_SEG_MAX_EXTENT) {
+            rc = batch_decompress_segments(st, stream, who, d_out, d_out_stride, cap32, out_len, (uint32_t *)d_len, d_in, d_in_stride,
+                                           in_len_each, (uint32_t)in_len, nblocks);
+            if (rc != LZS_OK) goto done;
+            segmented = 1;
+        }
+    }
+    if (!segmented) {
+        HIP_TRY(launch(d_out, d_out_stride, cap32, (uint32_t *)d_len, d_in, d_in_stride,
+                       (const uint32_t *)d_in_len, (uint32_t)in_len, (uint32_t)nblocks, stream), who);
+        HIP_TRY(lzs_hip_d2h(out_len, d_len, sizeof(uint32_t) * nblocks, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+    }
     /* copy back only what each block produced: nothing past out_len[b] is touched */
     if (nblocks < 16) {
         for (size_t b = 0; b < nblocks; b++)
@@ -376,7 +407,6 @@ static double now_ms(void)
 #define STREAM_SEG_MAX 65536u
 #define STREAM_SEG_MIN 4096u
 #define STREAM_MIN   24576u                     /* shorter inputs stay with one workgroup */
-#define STREAM_DEC_MIN 4096u                    /* shorter streams are decompressed by one wavefront */
 
 /* Segment size for a stream of n bytes: 64 KiB for long streams, smaller for shorter ones so that
  * they too spread over the device -- a workgroup takes ~1.2 ms per 64 KiB, and every segment pays
@@ -681,7 +711,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !getenv("LZS_NO_MARKS"), seg, concat, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !getenv("LZS_NO_MARKS"), seg, concat, NULL, NULL, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
@@ -736,7 +766,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         memset(dirty, 1, nseg);
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
-        HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count, NULL, NULL, 0, seg, concat, stream), who);
+        HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count, NULL, NULL, 0, seg, concat, NULL, NULL, stream), who);
         HIP_TRY(lzs_hip_d2h(ex2, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(cn2, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -772,7 +802,7 @@ static size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, siz
         HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
         HIP_TRY(lzs_hip_launch_decode_stream(d_out, before + produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
-                                             ndec, d_entry, d_start, seg, concat, stream), who);
+                                             ndec, d_entry, d_start, seg, concat, NULL, NULL, NULL, NULL, stream), who);
         uint32_t open[2] = {0, 0};
         HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -803,6 +833,132 @@ done:
     { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
     if (status) *status = rc;
     return result;
+}
+
+/* A batch of blocks decompressed like one long stream: every block is cut into segments of its
+ * own (tables tell the kernels where a segment starts, where its stream ends, where its block's
+ * output begins and must end), the scan rounds run over all of them at once -- a block's first
+ * segment is always entered at bit 0 in the normal state -- and the origins are resolved over the
+ * whole strided output.  d_in / d_out are the staged device buffers of host_batch(). */
+static int batch_decompress_segments(staging_t *st, void *stream, const char *who, void *d_out, size_t d_out_stride,
+                                     uint32_t cap32, uint32_t *out_len, uint32_t *d_len, const void *d_in, size_t d_in_stride,
+                                     const uint32_t *in_len_each, uint32_t in_len, size_t nblocks)
+{
+    int e = 0, rc = LZS_OK;
+    size_t total_in = 0;
+    for (size_t b = 0; b < nblocks; b++) total_in += in_len_each ? in_len_each[b] : in_len;
+    const uint32_t seg = stream_dec_seg(total_in / 4);        /* (smaller than for one stream of that size: measured) */
+    uint32_t nseg = 0;
+    for (size_t b = 0; b < nblocks; b++) nseg += ((in_len_each ? in_len_each[b] : in_len) + seg - 1) / seg;
+    const uint32_t extent = (uint32_t)(nblocks * d_out_stride);
+    memset(out_len, 0, sizeof(uint32_t) * nblocks);
+    if (nseg == 0) return LZS_OK;
+    /* host tables: 12 words and 3 bytes per segment */
+    uint32_t *tab = (uint32_t *)malloc((size_t)nseg * (12 * 4 + 4));
+    if (!tab) return fail(LZS_E_NOMEM, "%s: out of host memory", who);
+    uint32_t *entry = tab, *exits = entry + nseg, *count = exits + nseg, *start = count + nseg;
+    uint32_t *base = start + nseg, *end = base + nseg, *floor_ = end + nseg, *limit = floor_ + nseg;
+    uint32_t *seen = limit + nseg, *blk = seen + nseg, *spare = blk + nseg;   /* (spare: two unused rows) */
+    uint8_t *dirty = (uint8_t *)(spare + 2 * (size_t)nseg), *ones = dirty + nseg, *first = ones + nseg;
+    void *d_aux = NULL, *d_marks = NULL, *d_origin = NULL;
+#define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto done; } } while (0)
+    e = staging_reserve(st, BUF_AUX, (size_t)nseg * (8 * 4 + 2) + 128, &d_aux);
+    if (!e) e = staging_reserve(st, BUF_MARKS, (size_t)nseg * LZS_SCAN_MARK_WORDS * 4u, &d_marks);
+    if (!e) e = staging_reserve(st, BUF_KEEP, 4 * (size_t)extent + 64, &d_origin);
+    if (e) { rc = fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
+    uint32_t *d_entry = (uint32_t *)d_aux, *d_exit = d_entry + nseg, *d_count = d_exit + nseg, *d_start = d_count + nseg;
+    uint32_t *d_base = d_start + nseg, *d_end = d_base + nseg, *d_floor = d_end + nseg, *d_limit = d_floor + nseg;
+    uint32_t *d_counters = d_limit + nseg;
+    uint8_t *d_dirty = (uint8_t *)(d_counters + 2), *d_ones = d_dirty + nseg;
+    {
+        uint32_t k = 0;
+        for (size_t b = 0; b < nblocks; b++) {
+            const uint32_t len = in_len_each ? in_len_each[b] : in_len;
+            for (uint32_t at = 0; at < len; at += seg, k++) {
+                base[k] = (uint32_t)(b * d_in_stride) + at;
+                end[k] = (uint32_t)(b * d_in_stride) + len;
+                floor_[k] = (uint32_t)(b * d_out_stride);
+                limit[k] = floor_[k] + cap32;
+                blk[k] = (uint32_t)b;
+                first[k] = at == 0;
+                entry[k] = 0; dirty[k] = 1; seen[k] = 0xFFFFFFFFu;
+            }
+        }
+    }
+    const int debug = getenv("LZS_STREAM_DEBUG") != NULL;
+    double t0 = debug ? now_ms() : 0, t1;
+    HIP_TRY(lzs_hip_h2d(d_base, base, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+    HIP_TRY(lzs_hip_h2d(d_end, end, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+    for (uint32_t round = 0, ndirty = nseg; ndirty; round++) {
+        HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
+        HIP_TRY(lzs_hip_launch_scan_stream(d_in, 0, nseg, d_entry, d_dirty, d_exit, d_count, round == 0 ? d_ones : NULL,
+                                           (uint32_t *)d_marks, round != 0, seg, 0, d_base, d_end, stream), who);
+        HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        for (uint32_t k = 0; k < nseg; k++) if (dirty[k]) seen[k] = entry[k];
+        ndirty = 0;
+        int ended = 0, settled = 1;
+        for (uint32_t k = 0; k < nseg; k++) {                  /* as in stream_decompress(), block by block */
+            dirty[k] = 0;
+            if (first[k]) { ended = 0; settled = 1; continue; }
+            uint32_t want = exits[k - 1];
+            if (want & LZS_SEG_STOP) { if (settled) ended = 1; else want = entry[k]; }
+            if (ended) want = LZS_SEG_STOP;
+            if (want != entry[k]) settled = 0;
+            entry[k] = want;
+            if (ended || want == seen[k]) continue;
+            if (((want >> 8) & 1u) && (ones[k] == 2 || (ones[k] && (want & 3u) == 0))) {
+                const uint32_t r = want & 0xFFu;
+                const uint32_t nibbles = (seg * 8u - r + 3u) / 4u;
+                exits[k] = (want & ~0xFFu) | (r + 4u * nibbles - seg * 8u);
+                count[k] = 15u * nibbles;
+                seen[k] = want;
+                continue;
+            }
+            dirty[k] = 1;
+            ndirty++;
+        }
+        if (ndirty) {
+            HIP_TRY(lzs_hip_h2d(d_exit, exits, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+            HIP_TRY(lzs_hip_h2d(d_count, count, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+        }
+        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs batch decode: %zu blocks, %u segments of %u; round %u in %.2f ms, %u to redo\n", nblocks, nseg, seg, round, t1 - t0, ndirty); t0 = t1; }
+    }
+    {
+        uint64_t total = 0;
+        for (uint32_t k = 0; k < nseg; k++) {
+            if (first[k]) total = 0;
+            start[k] = floor_[k] + (uint32_t)(total < cap32 ? total : cap32);
+            if (!(entry[k] & LZS_SEG_STOP)) total += count[k];
+            out_len[blk[k]] = (uint32_t)(total < cap32 ? total : cap32);
+        }
+    }
+    HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+    HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+    HIP_TRY(lzs_hip_h2d(d_floor, floor_, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+    HIP_TRY(lzs_hip_h2d(d_limit, limit, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
+    HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
+    HIP_TRY(lzs_hip_memset(d_origin, 0xFF, 4 * (size_t)extent, stream), "hipMemset");      /* everything "clean" */
+    HIP_TRY(lzs_hip_launch_decode_stream(d_out, extent, (uint32_t *)d_origin, d_counters, d_in, 0, nseg, d_entry, d_start,
+                                         seg, 0, d_base, d_end, d_floor, d_limit, stream), who);
+    {
+        uint32_t open[2] = {0, 0};
+        HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs batch decode: tables + memset + decode in %.2f ms, %u bytes with an origin elsewhere\n", t1 - t0, open[0]); t0 = t1; }
+        /* origins never leave their block: one workgroup per block resolves them to the end */
+        HIP_TRY(lzs_hip_h2d(d_len, out_len, sizeof(uint32_t) * nblocks, stream), "hipMemcpy H2D");
+        if (open[0]) HIP_TRY(lzs_hip_launch_resolve_blocks(d_out, (uint32_t *)d_origin, d_out_stride, d_len, (uint32_t)nblocks, stream), who);
+        HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
+        if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs batch decode: resolve in %.2f ms\n", t1 - t0); t0 = t1; }
+    }
+#undef HIP_TRY
+done:
+    free(tab);
+    return rc;
 }
 
 int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len, const void *d_in, size_t in_len)

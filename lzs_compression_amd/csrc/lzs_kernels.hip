@@ -2111,9 +2111,9 @@ struct DecSegLds {
 };
 
 template <bool DECODE>
-__device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ in, uint32_t n, uint32_t k, uint32_t entry,
+__device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ in, uint32_t n, uint32_t seg_byte, uint32_t entry,
                                                    uint32_t *exit_out, uint32_t *count_out,
-                                                   uint8_t *out, uint32_t cap, uint32_t out_start,
+                                                   uint8_t *out, uint32_t cap, uint32_t out_start, uint32_t out_floor,
                                                    uint32_t *origin_g, uint32_t *tainted_total,
                                                    DecSegLds *Lp, uint32_t lane, uint32_t kDecSeg, bool concat,
                                                    uint32_t *marks = nullptr, bool compare = false)
@@ -2121,10 +2121,13 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
     const uint32_t kDecEnd = 8u * kDecSeg;                        // the segment's length in bits
     // SCAN only.  A walk that is repeated from another entry falls in step with the walk before
     // after a few dozen tokens, and from there on it IS that walk: a full walk leaves behind its
-    // first 64 token starts (state word and bytes produced so far: `marks`), and a repeated one
+    // 64 of its token starts (state word and bytes produced so far: `marks`), and a repeated one
     // stops as soon as it stands on one of them -- it leaves as the full walk left, with that
-    // walk's byte count from there on.  (Otherwise every round costs a walk over all 8 KiB.)
-    uint32_t my_mark = ~0u, my_count = 0, nmark = 0;
+    // walk's byte count from there on.  (Otherwise every round costs a walk over the whole
+    // segment.)  The marks are the first 16 steps of the walk, then every 2nd, 4th, .. 64th, eight
+    // of each: two walks in step take the same steps, so the repeated one meets the next mark
+    // within that many, and the marks reach a thousand steps into the segment.
+    uint32_t my_mark = ~0u, my_count = 0, nmark = 0, iter = 0, next_mark = 0, mark_step = 1;
     uint32_t old_mark = ~0u, old_count = 0, old_last = 0;
     bool checking = false, merged = false;
     if (!DECODE && compare) {
@@ -2138,7 +2141,7 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
     uint8_t *ring8 = DECODE ? reinterpret_cast<uint8_t *>(Lp->ring) : nullptr;
     uint16_t *origin = DECODE ? Lp->origin : nullptr;
     const uint32_t rel0 = entry & 0xFFu;
-    const uint32_t byte0 = kDecSeg * k + (rel0 >> 3);
+    const uint32_t byte0 = seg_byte + (rel0 >> 3);              // (the segment starts at in[seg_byte], its stream ends at in[n])
     uint32_t count = 0, flushed = 0, tainted = 0;
     uint32_t off = (entry >> 9) & 0x7FFu;
     uint32_t extended = (entry >> 8) & 1u;
@@ -2192,11 +2195,14 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                     }
                     if (cur > old_last) checking = false;
                 }
-                if (nmark < 64u) {
+                if (nmark < 64u && iter == next_mark) {
                     my_mark = lane == nmark ? word : my_mark;
                     my_count = lane == nmark ? count : my_count;
+                    if (nmark >= 15u && ((nmark - 15u) & 7u) == 0u) mark_step <<= 1;
+                    next_mark += mark_step;
                     nmark++;
                 }
+                iter++;
             }
             if (have == 0u) break;                               // input exhausted (:189)
             if (DECODE && out_start + count >= cap) break;       // output full (:200)
@@ -2278,9 +2284,9 @@ __device__ __forceinline__ void lzs_stream_segment(const uint8_t *__restrict__ i
                         if (from >= off) {                       // inside this segment's own output
                             const uint32_t at = (from - off) & kRingMask;
                             v = ring8[at]; og = origin[at];
-                        } else if ((unsigned long long)out_start + from >= off) {
+                        } else if ((unsigned long long)out_start + from >= (unsigned long long)off + out_floor) {
                             og = off - from;                     // produced by another wave: that far before my output
-                        }                                        // else before out[0]: zero (:350-357)
+                        }                                        // else before the stream's out[0] (out_floor): zero (:350-357)
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (lane < copy_len) {
@@ -2329,29 +2335,34 @@ void lzs_scan_stream_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t
                             const uint32_t *__restrict__ entry, const uint8_t *__restrict__ dirty,
                             uint32_t *__restrict__ exit_state, uint32_t *__restrict__ count,
                             uint8_t *__restrict__ all_ones, uint32_t *__restrict__ marks, uint32_t compare,
-                            uint32_t kDecSeg, uint32_t concat)
+                            uint32_t kDecSeg, uint32_t concat,
+                            const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_end)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * 4u + uniform(threadIdx.x >> 6);
     if (k >= nseg) return;
+    // one stream cut into equal segments -- or many streams in one buffer (a batch of blocks), each
+    // cut into segments of its own: then the tables say where segment k starts and its stream ends
+    const uint32_t sbase = seg_base ? uniform(seg_base[k]) : k * kDecSeg;
+    if (seg_end) n = uniform(seg_end[k]);
     if (all_ones) {
         // A whole segment of 0xFF bytes inside a running extension is nothing but nibbles of 15:
         // it leaves in the state in which it was entered.  The host uses this to carry a long
         // match across its segments without a round each.
-        bool ones = (size_t)(k + 1u) * kDecSeg <= n;
+        bool ones = (size_t)sbase + kDecSeg <= n;
         if (ones) {
-            const uint8_t *p = in + (size_t)k * kDecSeg;
+            const uint8_t *p = in + sbase;
             for (uint32_t i = lane; i < kDecSeg && ones; i += 64u) ones = p[i] == 0xFFu;
         }
         const bool all = __builtin_amdgcn_ballot_w64(!ones) == 0ull;
         // 2: and so are the first three bits after it (the last nibble that starts in the segment
         // may reach that far into the next one)
-        const size_t after = (size_t)(k + 1u) * kDecSeg;
+        const size_t after = (size_t)sbase + kDecSeg;
         if (lane == 0) all_ones[k] = !all ? 0 : (after < n && (in[after] & 0xE0u) == 0xE0u) ? 2 : 1;
     }
     if (dirty && !dirty[k]) return;
-    lzs_stream_segment<false>(in, n, k, uniform(entry[k]), exit_state + k, count + k,
-                              nullptr, 0, 0, nullptr, nullptr, nullptr, lane, kDecSeg, concat != 0u,
+    lzs_stream_segment<false>(in, n, sbase, uniform(entry[k]), exit_state + k, count + k,
+                              nullptr, 0, 0, 0, nullptr, nullptr, nullptr, lane, kDecSeg, concat != 0u,
                               marks ? marks + (size_t)k * kScanMarkWords : nullptr, compare != 0u);
 }
 
@@ -2360,7 +2371,9 @@ void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t 
                               uint32_t *__restrict__ tainted_total,
                               const uint8_t *__restrict__ in, uint32_t n, uint32_t nseg,
                               const uint32_t *__restrict__ entry, const uint32_t *__restrict__ out_start,
-                              uint32_t kDecSeg, uint32_t concat)
+                              uint32_t kDecSeg, uint32_t concat,
+                              const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_end,
+                              const uint32_t *__restrict__ out_floor, const uint32_t *__restrict__ out_limit)
 {
     __shared__ DecSegLds lds[4];
     const uint32_t lane = threadIdx.x & 63u;
@@ -2369,7 +2382,11 @@ void lzs_decode_stream_kernel(uint8_t *__restrict__ out, uint32_t cap, uint32_t 
     if (k >= nseg) return;
     const uint32_t e = uniform(entry[k]);
     if (e & kSegStop) return;                                 // the stream ended before this segment
-    lzs_stream_segment<true>(in, n, k, e, nullptr, nullptr, out, cap, uniform(out_start[k]),
+    const uint32_t sbase = seg_base ? uniform(seg_base[k]) : k * kDecSeg;
+    if (seg_end) n = uniform(seg_end[k]);
+    if (out_limit) cap = uniform(out_limit[k]);                // where this segment's stream must stop writing
+    lzs_stream_segment<true>(in, n, sbase, e, nullptr, nullptr, out, cap, uniform(out_start[k]),
+                             out_floor ? uniform(out_floor[k]) : 0u,
                              origin_g, tainted_total, &lds[wv], lane, kDecSeg, concat != 0u);
 }
 
@@ -2394,6 +2411,37 @@ void lzs_resolve_stream_kernel(uint8_t *__restrict__ out, uint32_t *__restrict__
         }
     }
     if (open) atomicAdd(left, open);
+}
+
+// The same for a batch of blocks (lzs_decompress_batch of a small batch: every block cut into
+// segments): origins never leave their block, so one workgroup per block jumps pointers until its
+// block is done, with barriers instead of launches between the rounds.  In place: a byte whose
+// origin is clean takes its value and becomes clean itself (value first, then the mark: release /
+// acquire at workgroup scope), any other adopts its origin's origin -- whichever of the two a
+// neighbour reads meanwhile is a valid origin of that byte.
+__global__ __launch_bounds__(1024)
+void lzs_resolve_blocks_kernel(uint8_t *__restrict__ out, uint32_t *__restrict__ origin_g, size_t out_stride,
+                               const uint32_t *__restrict__ len)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = len[b];
+    const uint32_t base = (uint32_t)(b * out_stride);
+    for (;;) {
+        int pending = 0;
+        for (uint32_t p = base + threadIdx.x; p < base + n; p += 1024u) {
+            const uint32_t o = origin_g[p];
+            if (o == kClean) continue;
+            const uint32_t oo = __hip_atomic_load(&origin_g[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (oo == kClean) {
+                out[p] = out[o];
+                __hip_atomic_store(&origin_g[p], kClean, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                origin_g[p] = oo;
+                pending = 1;
+            }
+        }
+        if (!__syncthreads_or(pending)) break;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -2749,22 +2797,34 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones, uint32_t *d_marks, int compare, uint32_t seg, int concat,
-                               void *stream)
+                               const uint32_t *d_seg_base, const uint32_t *d_seg_end, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones,
-                       d_marks, compare ? 1u : 0u, seg, concat ? 1u : 0u);
+                       d_marks, compare ? 1u : 0u, seg, concat ? 1u : 0u, d_seg_base, d_seg_end);
     return (int)hipGetLastError();
 }
 
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
-                                 const uint32_t *d_out_start, uint32_t seg, int concat, void *stream)
+                                 const uint32_t *d_out_start, uint32_t seg, int concat,
+                                 const uint32_t *d_seg_base, const uint32_t *d_seg_end,
+                                 const uint32_t *d_out_floor, const uint32_t *d_out_limit, void *stream)
 {
     if (nseg == 0) return 0;
     hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u);
+                       (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
+                       d_seg_base, d_seg_end, d_out_floor, d_out_limit);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_resolve_blocks(void *d_out, uint32_t *d_origin, size_t out_stride, const uint32_t *d_len,
+                                  uint32_t nblocks, void *stream)
+{
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(lzs_resolve_blocks_kernel, dim3(nblocks), dim3(1024), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, d_origin, out_stride, d_len);
     return (int)hipGetLastError();
 }
 

@@ -493,6 +493,25 @@ def test_short_streams_decompressed_by_many_wavefronts_in_small_segments():
         assert lzs.decompress(ones, 30 * n + 100) == O.decompress(ones, 30 * n + 100)
 
 
+def test_small_batches_decompressed_in_segments():
+    """lzs_decompress_batch() of a batch too small to fill the device with a wavefront per block
+    cuts every block into segments for many wavefronts (4 blocks: 0.7 ms instead of 8): ragged
+    blocks of every kind, empty ones, a capacity that cuts some of them, garbage and truncated
+    streams in between -- block b is lzs_decompress() of block b alone, as the oracle does it."""
+    rng = np.random.default_rng(21)
+    text = bytes(workload.fill("text", 4).reshape(-1))
+    plains = [text[:70000], b"", bytes(90000), text[100:5000], bytes(rng.integers(0, 256, 30000, dtype=np.uint8)),
+              b"ab" * 20000 + text[:100], text[:1], bytes(workload.fill("lowent", 1).reshape(-1)), text[5000:66000]]
+    streams = [O.compress(p) for p in plains]
+    streams.append(bytes(rng.integers(0, 256, 20000, dtype=np.uint8)))           # garbage
+    streams.append(streams[0][:len(streams[0]) // 2])                            # truncated
+    streams.append(streams[4] + b"trailing bytes after the end marker")
+    for cap in (100000, 65536, 4097, 1):
+        got = _gpu_decompress_many(streams, cap)
+        for i, st in enumerate(streams):
+            assert got[i] == O.decompress(st, cap), (cap, i)
+
+
 def test_long_match_ending_at_a_segment_border_of_all_ones():
     """A long run is thousands of 1111 nibbles; a segment that is nothing but 0xFF inside a running
     extension is not walked, its exit is worked out by the host -- which is only right if the last
