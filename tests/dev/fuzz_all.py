@@ -78,6 +78,57 @@ def inc_decode(rng, stream):
     raise RuntimeError("no progress")
 
 
+# the REAL reference's incremental interface (oracle/_ref travels to the GPU box): packets finished
+# with an end marker on ONE parameter block, so that later packets refer back into earlier ones
+import ctypes, struct
+_REF = os.path.join(os.path.dirname(__file__), "..", "..", "oracle", "_ref", "liblzs_ref.so")
+REF = ctypes.CDLL(_REF) if os.path.exists(_REF) else None
+if REF:
+    REF.lzs_compress_incremental.restype = ctypes.c_size_t
+    REF.lzs_compress_incremental.argtypes = [ctypes.c_void_p, ctypes.c_bool]
+    REF.lzs_compress_init_full.argtypes = [ctypes.c_void_p]
+
+
+def ref_packets(packets):
+    raw = ctypes.create_string_buffer(14432)
+    REF.lzs_compress_init_full(ctypes.addressof(raw))
+    out = bytearray()
+    for data in packets:
+        src = ctypes.create_string_buffer(bytes(data), max(len(data), 1))
+        dst = ctypes.create_string_buffer(len(data) + len(data) // 8 + 64)
+        struct.pack_into("<QQQQ", raw, 0, ctypes.addressof(src), ctypes.addressof(dst), len(data), len(dst))
+        n, fin = 0, False
+        for _ in range(1000):
+            n += REF.lzs_compress_incremental(ctypes.addressof(raw), fin)
+            if raw.raw[32] & 4:
+                break
+            fin = struct.unpack_from("<Q", raw, 16)[0] == 0
+        else:
+            raise RuntimeError("the reference did not finish the packet")
+        out += dst.raw[:n]
+    return bytes(out)
+
+
+def our_packets(rng, packets):
+    c = lzs.IncrementalCompressor()
+    out = bytearray()
+    for data in packets:
+        lo, hi = rng.choice(((1, 50), (100, 5000), (5000, 300000)))
+        pos, pending, fin, status = 0, b"", False, 0
+        for _ in range(10 ** 7):
+            if not pending and not fin and pos < len(data):
+                pending = data[pos:pos + rng.randint(lo, hi)]; pos += len(pending)
+            if not pending and pos >= len(data) and (status & 1 or not data):
+                fin = True
+            got, used, status = c.step(pending, rng.randint(max(lo, 3), hi), fin)
+            out += got; pending = pending[used:]
+            if status & 4:
+                break
+        else:
+            raise RuntimeError("no progress")
+    return bytes(out)
+
+
 t0, it = time.time(), 0
 ONLY = os.environ.get("FUZZ_ONLY")
 while time.time() - t0 < budget:
@@ -121,6 +172,20 @@ while time.time() - t0 < budget:
         cat = b"".join(O.compress(x) for x in parts)
         stage(seed, "concat", n=len(cat))
         assert lzs.decompress_concat(cat, sum(map(len, parts)) + 5) == b"".join(parts), "decompress_concat"
+        if REF:
+            packets = [make(rng, rng.choice((300, 5000, 40000))) for _ in range(rng.randint(1, 5))]
+            if rng.random() < 0.5 and packets[0]:
+                packets.append(packets[0][:len(packets[0]) // 2] + packets[-1][:777])     # refers far back
+            stage(seed, "packets", n=[len(x) for x in packets])
+            wantp = ref_packets(packets)
+            assert our_packets(rng, packets) == wantp, "packets with history kept over end markers (vs the reference)"
+            d2 = lzs.IncrementalDecompressor(); back = bytearray(); pend = wantp
+            for _ in range(10 ** 6):
+                got, used, status = d2.step(pend[:rng.randint(1, 70000)], rng.randint(1, 100000))
+                back += got; pend = pend[used:]
+                if not pend and status & 1:
+                    break
+            assert bytes(back) == b"".join(packets), "packets decoded back"
         stage(seed, "batch")
         nb = rng.randint(1, 40)
         blocks = [make(rng, 70000) for _ in range(nb)]

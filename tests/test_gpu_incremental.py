@@ -244,3 +244,56 @@ def test_large_pieces_decode_through_many_wavefronts():
                                    ((len(stream), len(stream)), (4096, 100000)), ((100000, 100000), (1 << 22, 1 << 22))):
         got, markers = _decode(stream, _rand(rng, ilo, ihi), _rand(rng, olo, ohi))
         assert got == want and markers == len(plains), (ilo, ihi, olo, ohi, len(got), markers)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "liblzs_ref.so")),
+                    reason="oracle/_ref/liblzs_ref.so was not built (needs /root/reference)")
+def test_random_packets_against_the_reference_library_itself():
+    """Where the compiled reference travelled along (oracle/_ref/liblzs_ref.so): random packets,
+    each finished with an end marker on ONE parameter block (history kept, so later packets refer
+    back), random piece sizes on our side -- byte for byte what the reference's own
+    lzs_compress_incremental() writes, and our decoder reads it back."""
+    import ctypes
+    import struct
+    ref = ctypes.CDLL(os.path.join(REFDIR, "liblzs_ref.so"))
+    ref.lzs_compress_incremental.restype = ctypes.c_size_t
+    ref.lzs_compress_incremental.argtypes = [ctypes.c_void_p, ctypes.c_bool]
+    ref.lzs_compress_init_full.argtypes = [ctypes.c_void_p]
+
+    def ref_packets(packets):
+        raw = ctypes.create_string_buffer(14432)            # the reference's LzsCompressParameters_t, as bytes
+        ref.lzs_compress_init_full(ctypes.addressof(raw))
+        out = bytearray()
+        for data in packets:
+            src = ctypes.create_string_buffer(bytes(data), max(len(data), 1))
+            dst = ctypes.create_string_buffer(len(data) + len(data) // 8 + 64)
+            struct.pack_into("<QQQQ", raw, 0, ctypes.addressof(src), ctypes.addressof(dst), len(data), len(dst))
+            n, fin = 0, False
+            for _ in range(1000):
+                n += ref.lzs_compress_incremental(ctypes.addressof(raw), fin)
+                if raw.raw[32] & api.STATUS_END_MARKER:
+                    break
+                fin = struct.unpack_from("<Q", raw, 16)[0] == 0
+            out += dst.raw[:n]
+        return bytes(out)
+
+    rng = random.Random(97)
+    text = _sample("text", 300000)
+    for it in range(25):
+        packets = []
+        for _ in range(rng.randint(1, 5)):
+            kind = rng.randint(0, 3)
+            n = rng.choice((0, 1, 40, 700, 9000, 60000))
+            a = rng.randint(0, len(text) - n - 1)
+            packets.append([text[a:a + n], bytes(n), rng.randbytes(n), (text[a:a + 50] * (n // 50 + 1))[:n]][kind])
+        if packets[0]:
+            packets.append(packets[0][:len(packets[0]) // 2] + b"!" + packets[-1][:333])
+        want = ref_packets(packets)
+        c, got = None, b""
+        for p in packets:
+            lo, hi = rng.choice(((1, 40), (200, 3000), (10000, 100000)))
+            part, c = _encode(p, _rand(rng, lo, hi), _rand(rng, max(lo, 3), hi), comp=c)
+            got += part
+        assert got == want, (it, [len(p) for p in packets])
+        back, markers = _decode(want, _rand(rng, 1, 50000), _rand(rng, 1, 80000), stop_at_markers=len(packets))
+        assert back == b"".join(packets) and markers == len(packets)
