@@ -2405,9 +2405,18 @@ void lzs_resolve_stream_kernel(uint8_t *__restrict__ out, uint32_t *__restrict__
         if (oo == kClean || (oo >= kDoneBase && (oo & 0xFFu) < round)) {
             out[p] = out[o];
             origin_g[p] = kDoneBase | round;
+        } else if (oo < kDoneBase) {
+            // two jumps a round: the origin's origin may be final already, or lead further back
+            const uint32_t ooo = origin_g[oo];
+            if (ooo == kClean || (ooo >= kDoneBase && (ooo & 0xFFu) < round)) {
+                out[p] = out[oo];
+                origin_g[p] = kDoneBase | round;
+            } else {
+                origin_g[p] = ooo < kDoneBase ? ooo : oo;         // adopt the farthest origin that is still open
+                open++;
+            }
         } else {
-            if (oo < kDoneBase) origin_g[p] = oo;                 // adopt the origin's origin
-            open++;
+            open++;                                               // the origin was resolved in this very round: next time
         }
     }
     if (open) atomicAdd(left, open);
