@@ -1,6 +1,6 @@
 /*
  * lzs_hip_shim.h -- the thin extern-"C" seam between the C host library
- * (lzs_host.c) and the HIP translation unit (lzs_kernels.hip).  Internal: not
+ * (lzs_host.c, lzs_stream.c, lzs_incremental.c) and the HIP translation unit (lzs_kernels.hip).  Internal: not
  * installed, not part of the public ABI (that is include/lzs/).
  *
  * Every function returns a hipError_t value as int (0 = hipSuccess) unless noted.

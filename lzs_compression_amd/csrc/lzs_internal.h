@@ -1,0 +1,77 @@
+/*
+ * lzs_internal.h -- what the host-side translation units of liblzs share (not installed).
+ *   lzs_host.c         errors, device batches, per-thread staging, host batches, the one-shot calls
+ *   lzs_stream.c       one stream (or a small batch) spread over the device: segments + stitch,
+ *                      scan / decode / resolve
+ *   lzs_incremental.c  the reference's incremental interface on top of both
+ */
+#ifndef LZS_INTERNAL_H
+#define LZS_INTERNAL_H
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "lzs/lzs.h"
+#include "lzs/lzs_batch.h"
+#include "lzs_hip_shim.h"
+
+#define LZS_HIDDEN __attribute__((visibility("hidden")))
+
+/* errors (lzs_host.c) */
+LZS_HIDDEN extern _Thread_local char tls_error[512];
+LZS_HIDDEN int fail(int code, const char *fmt, ...);
+LZS_HIDDEN int hip_fail(int hip_error, const char *what);
+LZS_HIDDEN int require_device(void);
+
+/* per-thread staging (lzs_host.c): one HIP stream and grow-only device buffers per host thread */
+enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_MARKS, BUF_COUNT };
+typedef struct {
+    void  *stream;
+    void  *buf[BUF_COUNT];
+    size_t cap[BUF_COUNT];
+    uint8_t *host_box;              /* host side of the small incremental calls' single copies */
+} staging_t;
+LZS_HIDDEN staging_t *staging_get(void);
+LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **out);   /* 0 or a hipError_t */
+LZS_HIDDEN void staging_trim(staging_t *st);
+LZS_HIDDEN double now_ms(void);
+
+/* thresholds of the one-shot calls */
+#define STREAM_MIN     24576u       /* shorter inputs are compressed by one workgroup */
+#define STREAM_DEC_MIN 4096u        /* shorter streams are decompressed by one wavefront */
+
+/* one stream on the whole device (lzs_stream.c) */
+typedef struct {                    /* a piece of a stream for lzs_compress_incremental(): see stream_compress_piece() */
+    const uint8_t *prefix;
+    uint32_t prefix_len;
+    uint32_t c0, ext_off, bit0;
+    uint8_t  first;
+    int      last;
+    /* results */
+    uint32_t c_exit;        /* everything before it is encoded */
+    uint32_t ext_exit;      /* != 0: still inside a long match at this offset */
+    uint64_t nbits;         /* bits in the output (bit0 included, end marker not) */
+} piece_t;
+typedef struct {                    /* a piece of a stream for lzs_decompress_incremental(): see stream_decompress() */
+    const uint8_t *prefix;
+    uint32_t prefix_len;
+    uint32_t entry0;
+    const uint8_t *hist;
+    uint32_t hist_len;
+    /* results */
+    uint32_t seg, segs_done;    /* segment size used; segments decoded */
+    uint32_t next_entry;        /* state word at the start of segment segs_done */
+} dec_piece_t;
+LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, piece_t *pc);
+LZS_HIDDEN size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status);
+LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, int concat,
+                                    dec_piece_t *dp);
+LZS_HIDDEN int batch_decompress_segments(staging_t *st, void *stream, const char *who, void *d_out, size_t d_out_stride,
+                                         uint32_t cap32, uint32_t *out_len, uint32_t *d_len, const void *d_in, size_t d_in_stride,
+                                         const uint32_t *in_len_each, uint32_t in_len, size_t nblocks);
+
+#endif
