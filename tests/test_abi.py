@@ -137,7 +137,7 @@ def test_product_does_not_reference_the_oracle():
     pkg = os.path.join(ROOT, "lzs_compression_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+            if f.endswith((".py", ".c", ".h", ".hip", ".inc", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in text and "liblzs_oracle" not in text \
                     and "oracle/" not in text.replace("SURVEY", ""), os.path.join(dirpath, f)
