@@ -68,6 +68,20 @@ int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, 
                                 size_t in_len, size_t nblocks, void *hip_stream);
 
 /*
+ * The same for a batch too small to fill the device with one wavefront per block (a wavefront
+ * needs 8-9 ms for a 64 KiB block whatever the batch): every block is cut into segments for many
+ * wavefronts (4 blocks 0.7 ms, 64 blocks 1.5 ms).  Buffers in device memory, but
+ * the lengths in HOST memory (in_len_each may be NULL: every block in_len bytes; out_len receives
+ * the results), and the call is synchronous: it runs on the calling thread's own stream, takes
+ * scratch memory from the thread's staging and returns when d_out is complete.  Batches beyond
+ * 32 MiB of output (or with blocks under 1 KiB on average) are handed to the one-wavefront-per-
+ * block kernel.
+ */
+int lzs_decompress_batch_device_sync(void *d_out, size_t out_stride, size_t out_cap, uint32_t *out_len,
+                                     const void *d_in, size_t in_stride, const uint32_t *in_len_each,
+                                     size_t in_len, size_t nblocks);
+
+/*
  * ONE stream from device memory, on the whole device: the result of
  * lzs_compress(d_out, out_cap, d_in, in_len) (reference lzs-compression.c:249-467) for buffers
  * already in HBM.  The stream is cut into 64 KiB segments, one workgroup each; where each

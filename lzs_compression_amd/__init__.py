@@ -6,10 +6,10 @@ the seeded workload generators used by the benchmark and tests.  No CPU codec, n
 fallback: without the built library or without a GPU, calls raise.
 """
 from .api import (IncrementalCompressor, IncrementalDecompressor, LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
-                  compress_stream, compressed_max, decompress, decompress_batch, decompress_blocks, decompress_concat,
+                  compress_stream, compressed_max, decompress, decompress_batch, decompress_blocks, decompress_blocks_sync, decompress_concat,
                   decompress_stream, decompressed_max, last_error, lib)
 from . import workload
 
 __all__ = ["IncrementalCompressor", "IncrementalDecompressor", "LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
-           "compress_stream", "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_concat",
+           "compress_stream", "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_blocks_sync", "decompress_concat",
            "decompress_stream", "decompressed_max", "last_error", "lib", "workload"]

@@ -63,7 +63,7 @@ def lib() -> ctypes.CDLL:
         for name in ("lzs_compress_batch_device", "lzs_decompress_batch_device"):
             f = getattr(L, name)
             f.restype, f.argtypes = ctypes.c_int, _BATCH_DEV
-        for name in ("lzs_compress_batch", "lzs_decompress_batch"):
+        for name in ("lzs_compress_batch", "lzs_decompress_batch", "lzs_decompress_batch_device_sync"):
             f = getattr(L, name)
             f.restype, f.argtypes = ctypes.c_int, _BATCH_HOST
         L.lzs_compress_stream_device.restype = ctypes.c_int
@@ -200,6 +200,26 @@ def compress_blocks(x, in_len=None, out_capacity: Optional[int] = None, out=None
 def decompress_blocks(x, in_len, out_capacity: int, out=None, out_len=None, stream=None):
     """Device batch of independent lzs_decompress() calls; arguments as compress_blocks."""
     return _device_batch(lib().lzs_decompress_batch_device, x, in_len, out_capacity, out, out_len, stream)
+
+
+def decompress_blocks_sync(x, in_len, out_capacity: int, out=None):
+    """lzs_decompress_batch_device_sync(): a SMALL batch of streams in device memory (``x``: uint8
+    [nblocks, stride]) with their lengths on the host (``in_len``: sequence / numpy array, or None
+    for full rows), every block cut into segments for many wavefronts.  Synchronous.  Returns
+    (out [nblocks, out_capacity] on the device, lengths as a numpy array)."""
+    import torch
+    assert x.is_cuda and x.dtype == torch.uint8 and x.dim() == 2 and x.stride(1) == 1
+    nblocks = x.shape[0]
+    if out is None:
+        out = torch.empty((nblocks, out_capacity), dtype=torch.uint8, device=x.device)
+    assert out.is_cuda and out.dtype == torch.uint8 and out.shape[0] == nblocks and out.stride(1) == 1
+    lens = None if in_len is None else np.ascontiguousarray(in_len, dtype=np.uint32)
+    out_len = np.zeros(nblocks, dtype=np.uint32)
+    torch.cuda.current_stream().synchronize()             # the call runs on the library's own stream
+    _check(lib().lzs_decompress_batch_device_sync(
+        out.data_ptr(), out.stride(0), out_capacity, out_len.ctypes.data,
+        x.data_ptr(), x.stride(0), None if lens is None else lens.ctypes.data, x.shape[1], nblocks))
+    return out, out_len
 
 
 def compress_stream(x, out=None):

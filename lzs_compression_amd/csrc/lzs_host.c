@@ -91,6 +91,51 @@ int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, 
                         out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, hip_stream);
 }
 
+int lzs_decompress_batch_device_sync(void *d_out, size_t out_stride, size_t out_cap, uint32_t *out_len,
+                                     const void *d_in, size_t in_stride, const uint32_t *in_len_each,
+                                     size_t in_len, size_t nblocks)
+{
+    const char *who = "lzs_decompress_batch_device_sync";
+    int rc = check_batch(who, out_len, d_in, in_len, nblocks);
+    if (rc != LZS_OK || nblocks == 0) return rc;
+    if (!d_out && out_cap) return fail(LZS_E_ARG, "%s: output is NULL", who);
+    size_t total_in = 0, longest = 0;
+    for (size_t b = 0; b < nblocks; b++) {
+        const size_t len = in_len_each ? in_len_each[b] : in_len;
+        total_in += len;
+        if (len > longest) longest = len;
+    }
+    if (longest > LZS_BLOCK_MAX) return fail(LZS_E_ARG, "%s: block exceeds LZS_BLOCK_MAX", who);
+    if ((rc = require_device()) != LZS_OK) return rc;
+    staging_t *st = staging_get();
+    if (!st) return fail(LZS_E_NOMEM, "%s: out of host memory", who);
+    int e = 0;
+    if (!st->stream && (e = lzs_hip_stream_create(&st->stream))) return hip_fail(e, "hipStreamCreate");
+    const uint32_t cap32 = out_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)out_cap;
+    void *d_len = NULL, *d_in_len = NULL;
+    if ((e = staging_reserve(st, BUF_LEN, sizeof(uint32_t) * nblocks, &d_len)))
+        return fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e));
+    if (cap32 && nblocks <= BATCH_SEG_MAX_BLOCKS && total_in >= STREAM_DEC_MIN && total_in / nblocks >= 1024u &&
+        (unsigned long long)nblocks * out_stride <= BATCH_SEG_MAX_EXTENT && (unsigned long long)nblocks * in_stride < 0xF0000000ull &&
+        cap32 <= out_stride) {
+        rc = batch_decompress_segments(st, st->stream, who, d_out, out_stride, cap32, out_len, (uint32_t *)d_len, d_in, in_stride,
+                                       in_len_each, (uint32_t)in_len, nblocks);
+    } else {
+        if (in_len_each) {
+            if ((e = staging_reserve(st, BUF_INLEN, sizeof(uint32_t) * nblocks, &d_in_len)))
+                return fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e));
+            if ((e = lzs_hip_h2d(d_in_len, in_len_each, sizeof(uint32_t) * nblocks, st->stream))) return hip_fail(e, "hipMemcpy H2D");
+        }
+        e = lzs_hip_launch_decompress(d_out, out_stride, cap32, (uint32_t *)d_len, d_in, in_stride, (const uint32_t *)d_in_len,
+                                      (uint32_t)in_len, (uint32_t)nblocks, st->stream);
+        if (!e) e = lzs_hip_d2h(out_len, d_len, sizeof(uint32_t) * nblocks, st->stream);
+        if (!e) e = lzs_hip_stream_sync(st->stream);
+        if (e) rc = hip_fail(e, who);
+    }
+    staging_trim(st);
+    return rc;
+}
+
 int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, size_t slot_stride,
                        const uint32_t *d_len, size_t nblocks, void *hip_stream)
 {
@@ -108,12 +153,6 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
  * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
  * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
 #define KEEP_MAX ((size_t)256 << 20)
-/* Batches up to this much output are decompressed in segments; larger ones fill the device with a
- * wavefront per block.  Measured (text, 64 KiB blocks, host buffers, ms; segments / wavefront per
- * block): 4 blocks 0.74 / 8.3, 64 blocks 1.5 / 8.5, 256 blocks 4.2 / 9.4, 512 blocks 11.4 / 13.4,
- * 1024 blocks 25.5 / 24.8. */
-#define BATCH_SEG_MAX_BLOCKS 4096u
-#define BATCH_SEG_MAX_EXTENT ((unsigned long long)32 << 20)
 
 
 static pthread_key_t  staging_key;

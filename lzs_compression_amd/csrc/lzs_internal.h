@@ -44,6 +44,13 @@ LZS_HIDDEN double now_ms(void);
 #define STREAM_MIN     24576u       /* shorter inputs are compressed by one workgroup */
 #define STREAM_DEC_MIN 4096u        /* shorter streams are decompressed by one wavefront */
 
+/* Batches up to this much output are decompressed in segments; larger ones fill the device with a
+ * wavefront per block.  Measured (text, 64 KiB blocks, host buffers, ms; segments / wavefront per
+ * block): 4 blocks 0.74 / 8.3, 64 blocks 1.5 / 8.5, 256 blocks 4.2 / 9.4, 512 blocks 11.4 / 13.4,
+ * 1024 blocks 25.5 / 24.8. */
+#define BATCH_SEG_MAX_BLOCKS 4096u
+#define BATCH_SEG_MAX_EXTENT ((unsigned long long)32 << 20)
+
 /* one stream on the whole device (lzs_stream.c) */
 typedef struct {                    /* a piece of a stream for lzs_compress_incremental(): see stream_compress_piece() */
     const uint8_t *prefix;

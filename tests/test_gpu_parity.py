@@ -611,3 +611,19 @@ def test_full_size_1gib_roundtrip_and_sampled_oracle(cls):
     assert (want_len == lens_h[sample]).all()
     for i in range(len(sample)):
         assert sub[i, :want_len[i]].tobytes() == want[i, :want_len[i]].tobytes()
+
+
+def test_small_batch_in_device_memory_decompressed_in_segments():
+    """lzs_decompress_batch_device_sync(): the segment route for batches whose buffers are already
+    in HBM (lengths on the host, synchronous).  Same results as the one-launch device call."""
+    for cls, nb in (("text", 7), ("lowent", 40), ("random", 3), ("text", 200)):
+        x = torch.from_numpy(workload.fill(cls, nb)).cuda()
+        slots, lens = lzs.compress_blocks(x)
+        torch.cuda.synchronize()
+        host_lens = lens.cpu().numpy()
+        for cap in (65536, 30000):
+            out, out_len = lzs.decompress_blocks_sync(slots, host_lens, cap)
+            ref, ref_len = lzs.decompress_blocks(slots, lens, cap)
+            torch.cuda.synchronize()
+            assert (out_len == ref_len.cpu().numpy()).all() and (out_len == cap).all()
+            assert torch.equal(out[:, :cap], ref[:, :cap]) and torch.equal(out[:, :cap], x[:, :cap])
