@@ -353,6 +353,59 @@ def test_one_shot_calls_from_many_host_threads():
     assert not errors, errors[:5]
 
 
+def test_segment_paths_and_incremental_calls_from_many_host_threads():
+    """The same for the paths that run rounds of launches with host decisions in between
+    (segments of one stream, scan / decode / resolve, small batches, the incremental interface):
+    each host thread has its own stream and staging buffers, so they must not disturb one another."""
+    import threading
+    rng = np.random.default_rng(12)
+    text = bytes(workload.fill("text", 8).reshape(-1))
+    datas = []
+    for i in range(18):
+        a = int(rng.integers(0, len(text) - 300_001))
+        d = text[a: a + int(rng.integers(30_000, 300_000))]
+        if i % 3 == 0:
+            d = d[:20_000] + bytes(int(rng.integers(1000, 90_000))) + d[20_000:]
+        datas.append(d)
+    want = [O.compress(d) for d in datas]
+    errors = []
+
+    def worker(tid):
+        try:
+            r = np.random.default_rng(100 + tid)
+            for i in range(tid, len(datas), 6):
+                d, w = datas[i], want[i]
+                if lzs.compress(d) != w or lzs.decompress(w, len(d) + 3) != d:
+                    errors.append((tid, i, "one-shot"))
+                c, out, pos = lzs.IncrementalCompressor(), b"", 0
+                while pos < len(d):
+                    k = int(r.integers(1000, 70_000))
+                    out += c.step(d[pos:pos + k], 200_000)[0]
+                    pos += k
+                out += c.step(b"", 200_000, True)[0]
+                if out != w:
+                    errors.append((tid, i, "incremental compress"))
+                dd, back, pend = lzs.IncrementalDecompressor(), b"", w
+                while pend:
+                    got, used, _ = dd.step(pend[:int(r.integers(1000, 70_000))], 500_000)
+                    back += got
+                    pend = pend[used:]
+                if back != d:
+                    errors.append((tid, i, "incremental decompress"))
+                got = _gpu_decompress_many([w, want[(i + 1) % len(want)]], 300_000)
+                if got != [d, datas[(i + 1) % len(datas)]]:
+                    errors.append((tid, i, "small batch"))
+        except Exception as e:      # noqa: BLE001 - collected for the assertion below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_multi_megabyte_single_stream():
     """One 3 MiB stream through the 4-argument call: positions well past 2^16 (16-bit head
     aliasing would show here) and a mix of the three classes, bit-exact vs the oracle."""
