@@ -7,7 +7,8 @@
  * way to process many buffers is a loop of such calls (c/src/test/test-lzs.c:111-114,
  * c/src/utils/lzs-compress.c:207).  Every function below is defined as exactly that
  * loop -- block b of a batch produces the bytes and the length that one reference call
- * on block b alone would -- executed by one GPU wavefront per block.
+ * on block b alone would -- executed by one GPU workgroup (compression) or wavefront
+ * (decompression) per block.
  *
  * All functions return LZS_OK (0) or a negative LZS_E_* code; lzs_last_error() gives
  * the message of the calling thread's most recent failure.  Plain C types only.
@@ -84,15 +85,16 @@ int lzs_decompress_batch_device_sync(void *d_out, size_t out_stride, size_t out_
 /*
  * ONE stream from device memory, on the whole device: the result of
  * lzs_compress(d_out, out_cap, d_in, in_len) (reference lzs-compression.c:249-467) for buffers
- * already in HBM.  The stream is cut into 64 KiB segments, one workgroup each; where each
+ * already in HBM.  The stream is cut into segments (4 KiB .. 64 KiB), one workgroup each; where each
  * segment's first token starts is agreed in a few rounds and the segments' bits are shifted to
  * their global offsets, so the bytes are those of the one-shot call.
  * The 4-argument lzs_compress() takes the same route for inputs of 24 KiB and more.
  *
  * d_out must be 4-byte aligned and hold LZS_COMPRESSED_MAX(in_len) + 1024 bytes; ALL of that is
  * overwritten (cleared first).  The result is cut at out_cap as lzs_compress() does.  The call
- * synchronises with the device several times (not capturable into a graph) and uses this thread's
- * staging stream.  Returns the byte count in *out_len.
+ * synchronises with the device several times (not capturable into a graph) and runs on this thread's
+ * own staging stream: d_in must be complete when the call is made (work queued on other streams is
+ * not waited for).  Returns the byte count in *out_len.
  */
 int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
                                const void *d_in, size_t in_len);
@@ -100,11 +102,12 @@ int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
 /*
  * The reverse: ONE stream in device memory decompressed by many wavefronts -- the result of
  * lzs_decompress(d_out, out_cap, d_in, in_len) (reference lzs-decompression.c:156-412: stops at
- * the first end marker, at out_cap, or when the bits run out).  The stream is cut into 8 KiB
- * segments that agree on the decoder state at their borders in a few rounds, decode with per-byte
+ * the first end marker, at out_cap, or when the bits run out).  The stream is cut into segments
+ * (256 bytes .. 8 KiB) that agree on the decoder state at their borders in a few rounds, decode with per-byte
  * origins for copies reaching into another segment's output, and resolve those by pointer jumping
  * (DESIGN.md 3.6).  The 4-argument lzs_decompress() takes the same route from 4 KiB of input on.  Output
- * below 4 GiB; allocates 4 * produced bytes of scratch on this thread's staging; synchronous.
+ * below 4 GiB; allocates 4 * produced bytes of scratch on this thread's staging; synchronous, on
+ * this thread's own stream (d_in must be complete when the call is made).
  */
 int lzs_decompress_stream_device(void *d_out, size_t out_cap, size_t *out_len,
                                  const void *d_in, size_t in_len);

@@ -54,6 +54,13 @@ def lib() -> ctypes.CDLL:
                 f"{_SO} is missing: the HIP library has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C lzs_compression_amd/csrc`).  There is no CPU fallback.")
+        # If PyTorch is installed, let it load ITS HIP runtime first: liblzs.so and torch must share
+        # one libamdhip64 in the process, and torch only finds its GPUs through the copy it ships
+        # (liblzs.so works with either).  Loaded the other way round, torch.cuda reports no devices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(_SO)
         for name in ("lzs_compress", "lzs_decompress", "lzs_decompress_concat"):
             f = getattr(L, name)
@@ -232,6 +239,7 @@ def compress_stream(x, out=None):
     if out is None:
         out = torch.empty(need, dtype=torch.uint8, device=x.device)
     got = _sz(0)
+    torch.cuda.current_stream().synchronize()             # the call runs on the library's own stream
     _check(lib().lzs_compress_stream_device(out.data_ptr(), out.numel(), ctypes.byref(got), x.data_ptr(), n))
     return out, int(got.value)
 
@@ -243,6 +251,7 @@ def decompress_stream(x, out_capacity, out=None):
     if out is None:
         out = torch.empty(out_capacity, dtype=torch.uint8, device=x.device)
     got = _sz(0)
+    torch.cuda.current_stream().synchronize()             # the call runs on the library's own stream
     _check(lib().lzs_decompress_stream_device(out.data_ptr(), out_capacity, ctypes.byref(got), x.data_ptr(), x.numel()))
     return out, int(got.value)
 

@@ -104,7 +104,8 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
         if (pre) HIP_TRY(lzs_hip_h2d(d_in, pc->prefix, pre, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + pre, in, n - pre, stream), "hipMemcpy H2D");
     }
-    HIP_TRY(lzs_hip_memset(d_out, 0, worst + 1024, stream), "hipMemset");
+    /* (a caller's device buffer is cleared only as far as it was promised: LZS_COMPRESSED_MAX(n) + 1024) */
+    HIP_TRY(lzs_hip_memset(d_out, 0, dev && worst + 1024 > cap ? cap : worst + 1024, stream), "hipMemset");
     if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs stream: %zu B, %u segments; H2D + memset %.2f ms\n", n, nseg, t1 - t0); t0 = t1; }
     uint32_t c_first = 0, ext_now = 0;
     uint64_t total = 0;

@@ -172,6 +172,22 @@ while time.time() - t0 < budget:
         cat = b"".join(O.compress(x) for x in parts)
         stage(seed, "concat", n=len(cat))
         assert lzs.decompress_concat(cat, sum(map(len, parts)) + 5) == b"".join(parts), "decompress_concat"
+        if len(d) >= 1:
+            import torch
+            sk_in, sk_out = rng.randint(0, 7), 4 * rng.randint(0, 3)          # any input alignment; output 4-aligned
+            x = torch.empty(len(d) + 8, dtype=torch.uint8, device="cuda")
+            x[sk_in:sk_in + len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+            buf = torch.empty(lzs.compressed_max(len(d)) + 1024 + 16, dtype=torch.uint8, device="cuda")
+            stage(seed, "device stream", n=len(d), sk_in=sk_in, sk_out=sk_out)
+            _, nb = lzs.compress_stream(x[sk_in:sk_in + len(d)], buf[sk_out:])
+            assert bytes(buf[sk_out:sk_out + nb].cpu().numpy()) == want, "compress_stream_device"
+            y = torch.empty(len(want) + 8, dtype=torch.uint8, device="cuda")
+            y[sk_in:sk_in + len(want)] = torch.frombuffer(bytearray(want), dtype=torch.uint8).cuda()
+            dcap = rng.choice((len(d) + 5, len(d), max(1, len(d) // 3)))
+            ob = torch.empty(dcap + 8, dtype=torch.uint8, device="cuda")
+            view = ob[rng.randint(0, 7):][:dcap]
+            _, got_n = lzs.decompress_stream(y[sk_in:sk_in + len(want)], dcap, view)
+            assert got_n == min(dcap, len(d)) and bytes(view[:got_n].cpu().numpy()) == d[:got_n], "decompress_stream_device"
         if REF:
             packets = [make(rng, rng.choice((300, 5000, 40000))) for _ in range(rng.randint(1, 5))]
             if rng.random() < 0.5 and packets[0]:
