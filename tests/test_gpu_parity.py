@@ -472,6 +472,29 @@ def test_stream_device_entry_point_1gib_text():
     assert n == x.numel() and torch.equal(back[:n], x.reshape(-1))
 
 
+def test_largest_stream_the_calls_accept():
+    """LZS_BLOCK_MAX (3 GiB, lzs_batch.h): one stream of exactly that size through
+    lzs_compress_stream_device() and back through lzs_decompress_stream_device() -- positions are
+    32-bit inside the kernels, this is where they are largest.  One byte more is refused."""
+    import torch
+    limit = 3 << 30
+    blocks = torch.from_numpy(workload.fill("text", 4096)).cuda().reshape(-1)           # 256 MiB of text ...
+    x = torch.empty(limit, dtype=torch.uint8, device="cuda")
+    for i in range(0, limit, blocks.numel()):                                           # ... twelve times,
+        x[i:i + blocks.numel()] = blocks
+    x[(1 << 30) + 5: (1 << 30) + 5 + (200 << 20)] = 7                                   # with a 200 MiB run inside
+    out, nbytes = lzs.compress_stream(x)
+    head = bytes(x[: 8 << 20].cpu().numpy())
+    want = O.compress(head)
+    assert bytes(out[: len(want) - 64].cpu().numpy()) == want[: len(want) - 64]
+    back, n = lzs.decompress_stream(out[:nbytes], limit + 16)
+    assert n == limit and torch.equal(back[:n], x)
+    del back
+    big = torch.empty(limit + 1, dtype=torch.uint8, device="cuda")
+    with pytest.raises(lzs.LzsError):
+        lzs.compress_stream(big)
+
+
 def test_one_long_stream_decompressed_by_many_wavefronts():
     """lzs_decompress() of a long stream is cut into 8 KiB segments, one wavefront
     each: the segments agree on the decoder state at their borders in a few rounds, decode with
