@@ -192,7 +192,9 @@ failed:
  * found no room.  Every call encodes what the data so far decides, as one piece of the stream
  * on the device (stream_compress_piece). */
 #define INC_HIST      2304u
-#define INC_CARRY_MAX 16u
+#define INC_CARRY_MAX 3600u         /* room for bytes not yet encoded ... */
+#define INC_ACCUM     3072u         /* ... small pieces are collected up to here before the device is asked */
+#define INC_UNDECIDED 15u           /* what a piece leaves undecided at most (LZS_MAX_LOOK_AHEAD_LEN) */
 #define INC_PEND_MAX  8192u
 typedef struct __attribute__((packed)) {
     uint32_t data_len;              /* bytes in data[]: history, then carry_len bytes not yet encoded */
@@ -269,8 +271,10 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
         const int last = add_end_marker && take == p->inLength;
         const size_t n = (size_t)pv->data_len + take;
         const uint32_t c0 = pv->data_len - pv->carry_len;
-        if (!last && n - c0 <= LZS_MAX_LOOK_AHEAD_LEN) {
-            /* too little to decide the next token (:641-647): it waits in the block */
+        if (!last && n - c0 <= INC_ACCUM) {
+            /* Too little to decide the next token (:641-647) -- or just little: a call costs
+             * ~0.12 ms whatever its size, so pieces like the reference tools' 512 bytes are
+             * collected in the block until there are 3 KiB of them (or the stream is finished). */
             memcpy(pv->data + pv->data_len, p->inPtr, take);
             pv->data_len += (uint32_t)take; pv->carry_len += (uint32_t)take;
             p->inPtr += take; p->inLength -= take;
@@ -287,7 +291,7 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
         const size_t got = stream_compress_piece(tmp, cap, p->inPtr, n, 0, &rc, &pc);
         if (rc != LZS_OK) goto failed_quiet;
         const size_t whole = last ? got : (size_t)(pc.nbits / 8);
-        if (whole > got || whole > room || pc.c_exit > n || pc.c_exit < c0 || (last ? pc.c_exit != n : n - pc.c_exit > INC_CARRY_MAX - 1u)) {
+        if (whole > got || whole > room || pc.c_exit > n || pc.c_exit < c0 || (last ? pc.c_exit != n : n - pc.c_exit > INC_UNDECIDED)) {
             fail(LZS_E_HIP, "%s: inconsistent state from the device (piece of %zu bytes from %u: %zu bytes out, %llu bits, ends at %u, room %zu)",
                  who, n, c0, got, (unsigned long long)pc.nbits, pc.c_exit, room);
             goto failed;
@@ -300,7 +304,7 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
         /* the new history and carry: bytes [c_exit - INC_HIST, n) of prefix + input */
         {
             const size_t from = pc.c_exit > INC_HIST ? pc.c_exit - INC_HIST : 0;
-            uint8_t keep[INC_HIST + INC_CARRY_MAX];
+            uint8_t keep[INC_HIST + INC_UNDECIDED + 1u];
             size_t k = 0;
             for (size_t i = from; i < n; ) {
                 if (i < pv->data_len) { const size_t m = (pv->data_len < n ? pv->data_len : n) - i; memcpy(keep + k, pv->data + i, m); k += m; i += m; }
