@@ -147,9 +147,10 @@ static inline void lzs_compress_init(LzsCompressParameters_t * pParams) { lzs_co
 
 /*
  * Compress the bytes at inPtr into outPtr (reference lzs-compression.c:553-823).  All input is
- * always taken (up to what the waiting output allows, below); tokens are emitted as soon as
- * they are decided, which takes 12 bytes of look-ahead (15 inside a long match), so up to 15
- * bytes are held back until more input arrives or add_end_marker is true.  With add_end_marker
+ * always taken (up to what the waiting output allows, below).  A token is decided once 12 bytes
+ * of look-ahead are there (15 inside a long match), so the last 15 bytes always wait for more
+ * input; and because a call that reaches the device costs the same whatever its size, input is
+ * collected in the block until 3 KiB are waiting.  add_end_marker flushes it all.  With add_end_marker
  * true and inLength 0 everything is flushed and the end marker written (status END_MARKER once
  * it is out); the history stays, so that a following stream may refer back (RFC 1974).
  * The concatenated output of any sequence of calls equals lzs_compress() of the concatenated
