@@ -244,6 +244,12 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
         p->status = LZS_C_STATUS_ERROR;
         return 0;
     }
+    /* no device, no stream: say so at the first call, not when the collected input is flushed */
+    if (require_device() != LZS_OK) {
+        fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+        p->status = LZS_C_STATUS_ERROR;
+        return 0;
+    }
     /* output still waiting from the call before goes first (:574-588) */
     if (pv->pend_pos < pv->pend_len) {
         const size_t have = pv->pend_len - pv->pend_pos;

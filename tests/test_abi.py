@@ -123,6 +123,8 @@ def test_incremental_calls_fail_loudly_without_a_gpu():
     with pytest.raises(lzs.LzsError) as e:
         c.step(b"hello hello hello hello hello", 100, True)
     assert "no HIP device" in str(e.value)
+    with pytest.raises(lzs.LzsError):                     # also for a piece that would only be collected
+        lzs.IncrementalCompressor().step(b"abc", 100, False)
     d = lzs.IncrementalDecompressor()
     with pytest.raises(lzs.LzsError):
         d.step(bytes.fromhex("30e07c3000"), 100)
