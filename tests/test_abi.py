@@ -58,6 +58,29 @@ int main(void) {
     assert out == ["73731", "4611", "160", "2047", "15", "1"]
 
 
+def test_headers_are_usable_from_cxx(tmp_path):
+    """Both headers in a C++ translation unit (extern "C" guards, no C-only constructs), linked
+    against the library."""
+    src = tmp_path / "t.cc"
+    src.write_text(r'''
+#include "lzs.h"
+#include "lzs_batch.h"
+#include <cstdio>
+int main() {
+    LzsCompressParameters_t c; LzsDecompressParameters_t d;
+    lzs_compress_init(&c); lzs_decompress_init(&d);
+    static_assert(sizeof(c) == 14432 && sizeof(d) == 2096, "the reference's sizes");
+    std::printf("%d %d\n", (int)c.status, (int)d.status);
+    return lzs_last_error() == nullptr;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", f"-I{INC}/lzs", str(src),
+                    f"-L{ROOT}/lzs_compression_amd", "-llzs",
+                    f"-Wl,-rpath,{ROOT}/lzs_compression_amd", "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split() == ["0", "0"]
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():
