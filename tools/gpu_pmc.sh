@@ -15,7 +15,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if 'lzs_compress' in r['Kernel_Name']:
+    if 'lzs_compress_blocks' in r['Kernel_Name']:   # (not the segment kernels of bench.py's single_stream line)
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in agg.items():
     print(f"  {k}: per-dispatch mean {sum(v)/len(v):.6g} over {len(v)} dispatches")
