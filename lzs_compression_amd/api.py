@@ -231,7 +231,7 @@ def decompress_blocks_sync(x, in_len, out_capacity: int, out=None):
 
 def compress_stream(x, out=None):
     """lzs_compress_stream_device(): the device tensor ``x`` (uint8, contiguous) as ONE LZS stream,
-    compressed by the whole device (segments of 64 KiB).  Returns
+    compressed by the whole device (segments of 4-64 KiB).  Returns
     (buffer uint8 [compressed_max(n) + 1024], nbytes); the stream is buffer[:nbytes].  Synchronous."""
     import torch
     n = x.numel()

@@ -8,7 +8,7 @@
 
 /* ------------------------------------------------ one long stream on the whole device */
 /* lzs_compress() of a buffer too long for one workgroup to be worth waiting for.  The search is a
- * pure function of (input, position), so the stream is cut into 64 KiB segments, one workgroup
+ * pure function of (input, position), so the stream is cut into segments (stream_seg()), one workgroup
  * each (lzs_compress_segments_kernel), every one writing its bits into a slot of its own.  What a
  * segment cannot know by itself is where its first token starts -- the last token of the segment
  * before usually reaches a few bytes into it -- and at which bit its output begins.  So: (1)
