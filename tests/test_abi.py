@@ -58,6 +58,15 @@ int main(void) {
     assert out == ["73731", "4611", "160", "2047", "15", "1"]
 
 
+def test_library_carries_the_reference_soname():
+    """libtool -version-info 4:0:0 (reference c/configure.ac:17, c/src/liblzs/Makefile.am:15) gives
+    liblzs.so.4: a program linked with -llzs against either build asks for that name at run time."""
+    so = os.path.join(ROOT, "lzs_compression_amd", "liblzs.so")
+    dyn = subprocess.run(["readelf", "-d", so], capture_output=True, text=True, check=True).stdout
+    assert "Library soname: [liblzs.so.4]" in dyn
+    assert os.path.exists(so + ".4")
+
+
 def test_headers_are_usable_from_cxx(tmp_path):
     """Both headers in a C++ translation unit (extern "C" guards, no C-only constructs), linked
     against the library."""
