@@ -326,3 +326,25 @@ class IncrementalDecompressor(_Incremental):
 
     def step(self, data: bytes, out_space: int):
         return self._call(lib().lzs_decompress_incremental, data, out_space)
+
+
+def incremental_compress(data: bytes, in_chunk: int, out_chunk: int) -> bytes:
+    """``data`` through lzs_compress_incremental() the way the reference's file tool drives it
+    (c/src/utils/lzs-compress.c:91-134): ``in_chunk`` bytes offered and ``out_chunk`` bytes of room
+    per call, unread input offered again, add_end_marker once the input is used up, until the
+    call reports END_MARKER.  Returns the whole stream."""
+    c, out, pos, piece, finish = IncrementalCompressor(), bytearray(), 0, b"", False
+    status, calls = 0, 0
+    while not (status & STATUS_END_MARKER):
+        if not piece and not finish:
+            piece = bytes(data[pos:pos + in_chunk])
+            pos += len(piece)
+        if not piece and (status & STATUS_INPUT_STARVED or pos >= len(data)):
+            finish = True
+        got, used, status = c.step(piece, out_chunk, finish)
+        out += got
+        piece = piece[used:]
+        calls += 1
+        if calls > 16 * (len(data) // max(1, min(in_chunk, out_chunk)) + 64):
+            raise LzsError(LZS_E_HIP, "lzs_compress_incremental makes no progress")
+    return bytes(out)

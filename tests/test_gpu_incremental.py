@@ -146,6 +146,26 @@ def test_golden_vector_encoded_in_pieces():
         assert got == comp
 
 
+def test_smoke_pattern_50_in_100_out():
+    """__graft_entry__.smoke()'s pattern: 50 bytes offered and 100 bytes of room per call, driven
+    like the reference's tool (utils/lzs-compress.c:91-134).  The compressor collects small pieces,
+    so most of the stream appears at the flush and must be drained over several calls."""
+    comp, plain = golden_bytes("kat_compressed_1.bin"), golden_bytes("kat_decompressed_1.bin")
+    assert lzs.incremental_compress(plain, 50, 100) == comp
+    assert lzs.incremental_compress(plain, 50, 3) == comp
+    assert lzs.incremental_compress(b"", 50, 100) == bytes.fromhex("c000")
+    # a single flush call into too little room reports NO_OUTPUT_BUFFER_SPACE, never END_MARKER
+    c = lzs.IncrementalCompressor()
+    out, used, status = c.step(plain, 100, True)
+    assert used == len(plain) and len(out) == 100 and out == comp[:100]
+    assert status & api.STATUS_NO_OUTPUT_BUFFER_SPACE and not status & api.STATUS_END_MARKER
+    rest = b""
+    while not status & api.STATUS_END_MARKER:
+        got, _, status = c.step(b"", 100, True)
+        rest += got
+    assert out + rest == comp
+
+
 @pytest.mark.parametrize("data,hexout", [
     (b"", "c000"), (b"a", "30e000"), (b"aa", "30987000"), (b"a" * 9, "30e07c3000"),
     (b"a" * 24, "30e07fc300"), (b"abcXabcYabc", "30988c658c2259c23800"),

@@ -14,5 +14,8 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/rocprof_bench.log 2>&1
 find $OUT/rocprof_stats -name '*stats*.csv' | head -5
 for f in $(find $OUT/rocprof_stats -name '*kernel_stats.csv'); do head -8 $f; done
+# the driver's acceptance hook, LAST: whatever changed during the session, smoke() ran after it
+cd $GRAFT_REPO_ROOT
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3 | tee $OUT/smoke.txt
 # keep the trace itself small: drop the per-dispatch csv if huge
 find $OUT -size +8M -delete
