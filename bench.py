@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- input GB/s of the LZS block-compression hot path on MI355X.
 
-A "step" is one pass of lzs_compress_batch_device over one batch of independent 64 KiB
+N = 1: a "step" is one pass of lzs_compress_batch_device over one batch of independent 64 KiB
 blocks already resident in HBM (BASELINE.json configs[1]: 1 GiB = 16384 blocks of
-enwik-style ASCII text per GPU).  Blocks shard across GPUs with no data-path collective
-(weak scaling: every rank compresses its own 1 GiB shard); `value` is the whole-job rate.
+enwik-style ASCII text).
+
+N > 1 (BASELINE.json configs[4]): 131072 blocks (8 GiB) per GPU --
+64 GiB at 8 GPUs -- generated in HBM on the root GPU by lzs_gen_blocks_kernel; a "step" is the
+whole job: SCATTER (root -> ranks, one batched group of RCCL point-to-point sends over xGMI),
+COMPRESS (every rank its shard; blocks are independent, no collective), GATHER (compaction +
+gather-v of the compressed streams and their lengths to the root).  `value` is the end-to-end
+rate of the whole job; the three phases are timed separately and the compute-only rate is
+reported next to it.  Weak scaling: per-GPU work is fixed.
 
     python bench.py                       # 1 GPU, text class
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -84,14 +91,124 @@ def cpu_baseline(blocks_host: np.ndarray, gpu_len: np.ndarray, gpu_slots) -> dic
             "gpu_output_bit_exact_on_sample": exact}
 
 
+def run_sharded(args, dist, rank: int, world: int, dev) -> None:
+    """N > 1: the config-5 job (lzs_compression_amd/sharded_job.py), K timed passes."""
+    from lzs_compression_amd.sharded_job import ShardedCompressJob
+    nb = args.blocks if args.blocks is not None else 131072
+    cap = lzs.compressed_max(BLOCK)
+    slot_stride = (cap + 15) // 16 * 16
+    kernel_ev = []
+
+    def compress(x, slots, lens):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        lzs.compress_blocks(x, None, cap, slots, lens)
+        b.record()
+        kernel_ev.append((a, b))
+
+    def compact(slots, lens, dense, offsets):
+        lzs.compact(slots, lens, dense=dense, offsets=offsets)
+        return int(offsets[-1].item())
+
+    job = ShardedCompressJob(nb, BLOCK, slot_stride, dev, compress, compact, torch.cuda.synchronize)
+    # ---- the root generates every rank's blocks in HBM, one piece (<= 8 GiB) per rank
+    pieces = None
+    t_gen = time.perf_counter()
+    if rank == 0:
+        pieces = [workload.fill_device(args.workload, nb, BLOCK, first_block=r * nb, device=dev) for r in range(world)]
+        torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step(pieces)
+    kernel_ev.clear()
+    barrier()
+    t0 = time.perf_counter()
+    phases = [job.step(pieces) for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # MAX over ranks of the job time and of every phase's mean
+    mean = {k: float(np.mean([p[k] for p in phases])) for k in ("scatter", "compress", "gather", "total")}
+    t = torch.tensor([elapsed, mean["scatter"], mean["compress"], mean["gather"], mean["total"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, sc, co, ga, tot = (float(v) for v in t.tolist())
+    kernel_ms = [a.elapsed_time(b) for a, b in kernel_ev]
+
+    # ---- checks outside the timed region: every rank decodes its own shard on the device ...
+    x = pieces[0] if rank == 0 else job.mine
+    back, back_len = lzs.decompress_blocks(job.slots, job.lens, BLOCK)
+    ok = bool((back_len == BLOCK).all()) and torch.equal(back[:, :BLOCK], x)
+    del back
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    lens_h = job.lens.cpu().numpy()
+    if rank == 0:
+        # ... and the root compares sampled blocks of EVERY rank's part of the gathered bytes with the
+        # CPU oracle (first, middle and last block of each shard), at the gathered offsets
+        import oracle
+        O = oracle.oracle()
+        all_lens = job.all_lens.cpu().numpy().astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(all_lens)])
+        gathered_ok = int(offs[-1]) == sum(job.counts) == int(job.out.numel())
+        for r in range(world):
+            for b in (0, nb // 2, nb - 1):
+                g = r * nb + b
+                got = bytes(job.out[int(offs[g]):int(offs[g + 1])].cpu().numpy())
+                gathered_ok = gathered_ok and got == O.compress(bytes(pieces[r][b].cpu().numpy()))
+        total_in = world * nb * BLOCK
+        in_bytes = nb * BLOCK
+        avg_ms = float(np.mean(kernel_ms))
+        achieved = in_bytes / (avg_ms * 1e-3) / 1e9
+        algo_bytes = in_bytes + int(lens_h.sum()) + 4 * nb
+        result = {
+            "metric": "input GB/s on 64KiB blocks, bit-exact vs C ref",
+            "value": total_in * args.steps / elapsed / 1e9,
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{world * nb} independent 64 KiB blocks ({world * nb * BLOCK >> 30} GiB / {world} GPUs), class "
+                                   f"'{args.workload}', generated in HBM on the root GPU, scattered {nb} blocks "
+                                   f"({nb * BLOCK >> 30} GiB) per rank over RCCL/xGMI, compressed, compacted, gathered to the root",
+                       "class": args.workload, "blocks_per_gpu": nb, "block_bytes": BLOCK,
+                       "sharding": f"contiguous block ranges, {nb} per rank; a step = scatter + compress + gather",
+                       "compression_ratio": float(all_lens.sum()) / total_in},
+            "phases_ms": {"scatter": sc * 1e3, "compress": co * 1e3, "gather": ga * 1e3, "step": tot * 1e3,
+                          "note": "mean over the timed steps, MAX over ranks; each phase ends with a device synchronize"},
+            "end_to_end_GBps": total_in * args.steps / elapsed / 1e9,
+            "compute_only_GBps": total_in / co / 1e9,
+            "scatter_GBps": (world - 1) * nb * BLOCK / sc / 1e9 if sc > 0 else None,
+            "gather_GBps": (sum(job.counts) - job.counts[0]) / ga / 1e9 if ga > 0 else None,
+            "gathered_bytes": int(sum(job.counts)),
+            "generate_on_root_s": t_gen,
+            "checks": {"every_rank_round_trip_on_device": bool(okt.item()), "gathered_samples_equal_oracle": bool(gathered_ok)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "lzs_compress_blocks_wg_kernel (rank 0's launches)",
+                         "algorithmic_bytes_per_launch": {"read_input": in_bytes, "total_read_plus_written": algo_bytes},
+                         "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms))},
+        }
+        print(json.dumps(result), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="text", choices=workload.CLASS_NAMES)
-    ap.add_argument("--blocks", type=int, default=16384, help="64 KiB blocks per GPU (16384 = 1 GiB)")
+    ap.add_argument("--blocks", type=int, default=None,
+                    help="64 KiB blocks per GPU (default: 16384 = 1 GiB at N = 1, 131072 = 8 GiB at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-job", action="store_true",
+                    help="run the N > 1 job (scatter / compress / gather over torch.distributed) even at N = 1: "
+                         "exercises that code path with the nccl backend on a one-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,11 +219,22 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.sharded_job:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     else:
         dist = None
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1 or args.sharded_job:
+        run_sharded(args, dist, rank, world, dev)
+        return
+    if args.blocks is None:
+        args.blocks = 16384
 
     # ---- this rank's shard: blocks [rank*nb, (rank+1)*nb) of the seeded class, into HBM
     nb = args.blocks
@@ -145,24 +273,6 @@ def main() -> None:
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
-    # N > 1: one compressed-output gather to rank 0 (compaction + RCCL gather-v), outside
-    # the timed steps and reported separately -- the compute path itself has no collective
-    gather = None
-    if dist is not None:
-        from lzs_compression_amd import sharding
-        try:
-            barrier()
-            g0 = time.perf_counter()
-            dense, offsets = lzs.compact(slots, lens)
-            nbytes = int(offsets[-1].item())
-            got, counts = sharding.gather_streams(dense, nbytes)
-            barrier()
-            gsec = time.perf_counter() - g0
-            gather = {"ms": gsec * 1e3, "bytes": int(sum(counts)), "GBps": sum(counts) / gsec / 1e9}
-            del dense, got
-        except Exception as e:          # the headline number must survive a gather failure
-            gather = {"error": repr(e)}
-
     total_in = world * nb * BLOCK * args.steps
     lens_h = lens.cpu().numpy()
     ratio = float(lens_h.sum()) / (nb * BLOCK)
@@ -200,8 +310,6 @@ def main() -> None:
                          "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
                          "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
         }
-        if gather is not None:
-            result["compressed_output_gather"] = gather
         if world == 1:
             # secondary, outside the timed region: the same bytes as ONE stream through
             # lzs_compress_stream_device, wall clock around the synchronous call

@@ -256,13 +256,18 @@ def decompress_stream(x, out_capacity, out=None):
     return out, int(got.value)
 
 
-def compact(slots, lengths, stream=None):
+def compact(slots, lengths, stream=None, dense=None, offsets=None):
     """Dense concatenation of the first lengths[b] bytes of every slot.
-    Returns (dense uint8 [sum], offsets int64 [nblocks+1]); asynchronous."""
+    Returns (dense uint8 [>= sum], offsets int64 [nblocks+1]); asynchronous.  ``dense`` /
+    ``offsets`` may be passed in for reuse (dense: at least nblocks * slot bytes)."""
     import torch
     nb = slots.shape[0]
-    offsets = torch.empty(nb + 1, dtype=torch.int64, device=slots.device)
-    dense = torch.empty(nb * slots.shape[1], dtype=torch.uint8, device=slots.device)
+    if offsets is None:
+        offsets = torch.empty(nb + 1, dtype=torch.int64, device=slots.device)
+    if dense is None:
+        dense = torch.empty(nb * slots.shape[1], dtype=torch.uint8, device=slots.device)
+    assert offsets.dtype == torch.int64 and offsets.numel() == nb + 1 and offsets.is_cuda
+    assert dense.dtype == torch.uint8 and dense.numel() >= nb * slots.shape[1] and dense.is_contiguous()
     _check(lib().lzs_compact_device(dense.data_ptr(), offsets.data_ptr(), slots.data_ptr(),
                                     slots.stride(0) if nb > 1 else slots.shape[1],
                                     lengths.data_ptr(), nb, _stream_handle(stream)))

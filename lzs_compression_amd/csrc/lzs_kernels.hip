@@ -38,7 +38,9 @@
 namespace {
 
 #include "kernels/common.inc"
+#ifdef LZS_WITH_VARIANTS   // the earlier compressors ("chain", "scan") and the v1 decoder: A/B builds only
 #include "kernels/compress_variants.inc"
+#endif
 #include "kernels/compress_wg.inc"
 #include "kernels/decompress_blocks.inc"
 #include "kernels/decompress_stream.inc"
@@ -93,25 +95,29 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
                             uint32_t in_len, uint32_t nblocks, void *stream)
 {
     if (nblocks == 0) return 0;
+#ifdef LZS_WITH_VARIANTS
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
-    // LZS_KERNEL selects a variant for A/B runs and cross-checks: "wg" (default, one
-    // workgroup per block), "chain" (one wave per block), "scan" (brute force)
+    // A/B builds only: LZS_KERNEL=chain (one wave per block) | scan (brute force) select the earlier kernels
     static const int variant = [] {
         const char *v = getenv("LZS_KERNEL");
         return !v ? 0 : (v[0] == 's' ? 2 : (v[0] == 'c' ? 1 : 0));
     }();
-    if (variant == 2)
+    if (variant == 2) {
         hipLaunchKernelGGL(lzs_compress_blocks_scan_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
-    else if (variant == 1)
+        return (int)hipGetLastError();
+    }
+    if (variant == 1) {
         hipLaunchKernelGGL(lzs_compress_blocks_kernel, dim3(nblocks), dim3(64), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
-    else
-        hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0,
-                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+        return (int)hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0,
+                       (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
     return (int)hipGetLastError();
 }
 
@@ -121,15 +127,18 @@ static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, u
 {
     if (nblocks == 0) return 0;
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
+#ifdef LZS_WITH_VARIANTS
     static const int use_v1 = [] { const char *v = getenv("LZS_DECODER"); return v && v[0] == 'v' && v[1] == '1'; }();
-    if (use_v1)
+    if (use_v1) {
         hipLaunchKernelGGL(lzs_decompress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
-    else
-        hipLaunchKernelGGL(lzs_decompress_blocks_v2_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
-                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
+        return (int)hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(lzs_decompress_blocks_v2_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                       (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
     return (int)hipGetLastError();
 }
 

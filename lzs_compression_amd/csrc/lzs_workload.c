@@ -209,7 +209,9 @@ static void gen_text(const vocab_t *v, uint8_t *dst, size_t len, uint64_t seed, 
             sentence_start = 1;
         } else if (kind < 60) {                 /* wiki link */
             wr_s(&w, "[[");
-            wr_word(&w, v, vocab_pick(v, &r, &topic), rng_below(&r, 2));
+            /* two draws for one call: the order is spelled out (gcc evaluated the last argument
+             * first; the committed digests and lzs_workload_gen.hip follow that order) */
+            { int cap = (int)rng_below(&r, 2); unsigned word = vocab_pick(v, &r, &topic); wr_word(&w, v, word, cap); }
             if (rng_below(&r, 3) == 0) { wr_c(&w, ' '); wr_word(&w, v, vocab_pick(v, &r, &topic), 0); }
             if (rng_below(&r, 4) == 0) { wr_c(&w, '|'); wr_word(&w, v, vocab_pick(v, &r, &topic), 0); }
             wr_s(&w, "]] ");
@@ -222,11 +224,11 @@ static void gen_text(const vocab_t *v, uint8_t *dst, size_t len, uint64_t seed, 
             wr_c(&w, ' ');
             sentence_start = 0;
         } else if (kind < 95) {                 /* number */
-            wr_num(&w, rng_below(&r, rng_below(&r, 2) ? 2100 : 100000));
+            { uint32_t range = rng_below(&r, 2) ? 2100 : 100000; wr_num(&w, rng_below(&r, range)); }
             wr_c(&w, ' ');
             sentence_start = 0;
         } else {                                /* plain word + separator */
-            wr_word(&w, v, vocab_pick(v, &r, &topic), sentence_start || rng_below(&r, 40) == 0);
+            { int cap = sentence_start || rng_below(&r, 40) == 0; unsigned word = vocab_pick(v, &r, &topic); wr_word(&w, v, word, cap); }
             sentence_start = 0;
             uint32_t sep = rng_below(&r, 100);
             if (sep < 8)       { wr_s(&w, ". "); sentence_start = 1; if (rng_below(&r, 5) == 0) wr_c(&w, '\n'); }
@@ -240,6 +242,20 @@ static void gen_text(const vocab_t *v, uint8_t *dst, size_t len, uint64_t seed, 
 }
 
 /* ------------------------------------------------------------ public API */
+/* The vocabulary as flat arrays (len[5000], txt[5000*14], cdf[5000]) for the device generator
+ * (lzs_workload_gen.hip), which must draw from the very same table. */
+int lzs_workload_vocab(uint8_t *len, char *txt, uint32_t *cdf)
+{
+    vocab_t *v = (vocab_t *)malloc(sizeof(vocab_t));
+    if (!v) return -1;
+    vocab_build(v);
+    memcpy(len, v->len, sizeof(v->len));
+    memcpy(txt, v->txt, sizeof(v->txt));
+    memcpy(cdf, v->cdf, sizeof(v->cdf));
+    free(v);
+    return 0;
+}
+
 typedef struct {
     const vocab_t *v;
     unsigned cls;

@@ -28,56 +28,98 @@ def shard_range(nblocks: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def scatter_blocks(blocks_on_root: Optional[torch.Tensor], nblocks: int, block_len: int,
-                   device: torch.device, src: int = 0, group=None) -> torch.Tensor:
-    """Root holds uint8 [nblocks, block_len]; every rank receives its shard_range rows.
-    Point-to-point sends issued as one batch, so the root drives all its links at once."""
+P2P_PIECE = 1 << 30      # bytes per point-to-point operation: shards and streams of several GiB go as pieces
+
+
+def _pieces(flat: torch.Tensor, piece: int):
+    """``flat`` (1-D uint8) cut into views of at most ``piece`` bytes."""
+    n = flat.numel()
+    return [flat[at:min(at + piece, n)] for at in range(0, n, piece)] if n else []
+
+
+def scatter_blocks(blocks_on_root, nblocks: int, block_len: int,
+                   device: torch.device, src: int = 0, group=None, out: Optional[torch.Tensor] = None,
+                   piece: int = P2P_PIECE) -> torch.Tensor:
+    """Root holds the blocks -- one uint8 tensor [nblocks, block_len], or a list with one tensor per
+    rank (rank r's rows: how bench.py generates 64 GiB in 8 GiB pieces) -- and every rank receives
+    its shard_range rows (into ``out`` if given).  All point-to-point sends of the root are issued
+    as ONE batch (one ncclGroup), so the root drives all its xGMI links at once; shards of several
+    GiB go as pieces of ``piece`` bytes inside that batch."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(nblocks, rank, world)
-    mine = torch.empty((hi - lo, block_len), dtype=torch.uint8, device=device)
+    mine = out if out is not None else torch.empty((hi - lo, block_len), dtype=torch.uint8, device=device)
+    assert tuple(mine.shape) == (hi - lo, block_len) and mine.dtype == torch.uint8 and mine.is_contiguous()
     ops = []
     if rank == src:
-        assert blocks_on_root is not None and tuple(blocks_on_root.shape) == (nblocks, block_len)
+        assert blocks_on_root is not None
+        per_rank = isinstance(blocks_on_root, (list, tuple))
+        if per_rank:
+            assert len(blocks_on_root) == world
+        else:
+            assert tuple(blocks_on_root.shape) == (nblocks, block_len)
         for r in range(world):
             rlo, rhi = shard_range(nblocks, r, world)
+            rows = blocks_on_root[r] if per_rank else blocks_on_root[rlo:rhi]
+            assert tuple(rows.shape) == (rhi - rlo, block_len)
             if r == src:
-                mine.copy_(blocks_on_root[rlo:rhi])
-            elif rhi > rlo:
-                ops.append(dist.P2POp(dist.isend, blocks_on_root[rlo:rhi].contiguous(), r, group))
-    elif hi > lo:
-        ops.append(dist.P2POp(dist.irecv, mine, src, group))
+                if rows.data_ptr() != mine.data_ptr():
+                    mine.copy_(rows)
+            else:
+                for v in _pieces(rows.contiguous().view(-1), piece):
+                    ops.append(dist.P2POp(dist.isend, v, r, group))
+    else:
+        for v in _pieces(mine.view(-1), piece):
+            ops.append(dist.P2POp(dist.irecv, v, src, group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return mine
 
 
-def gather_streams(dense: torch.Tensor, nbytes: int, dst: int = 0, group=None
-                   ) -> Tuple[Optional[torch.Tensor], List[int]]:
-    """Gather-v of compressed bytes: ``dense[:nbytes]`` of every rank lands on ``dst``,
-    concatenated in rank order.  Returns (bytes on dst | None elsewhere, per-rank counts)."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = torch.tensor([nbytes], dtype=torch.int64, device=dense.device)
-    counts_t = [torch.zeros(1, dtype=torch.int64, device=dense.device) for _ in range(world)]
+def gather_counts(nbytes: int, device: torch.device, group=None) -> List[int]:
+    """Every rank's byte count, on every rank (one all_gather of int64)."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([nbytes], dtype=torch.int64, device=device)
+    counts_t = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts_t, mine, group=group)
-    counts = [int(t.item()) for t in counts_t]
-    out = None
+    return [int(t.item()) for t in counts_t]
+
+
+def gather_streams(dense: torch.Tensor, nbytes: int, dst: int = 0, group=None,
+                   out: Optional[torch.Tensor] = None, piece: int = P2P_PIECE,
+                   counts: Optional[List[int]] = None) -> Tuple[Optional[torch.Tensor], List[int]]:
+    """Gather-v of compressed bytes: ``dense[:nbytes]`` of every rank lands on ``dst``,
+    concatenated in rank order (into ``out`` if given: uint8, at least the total).  Returns
+    (bytes on dst | None elsewhere, per-rank counts).  An all_gather of the byte counts (unless
+    the caller already has them: ``counts``), then one batch of point-to-point operations
+    (pieces of ``piece`` bytes)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if counts is None:
+        counts = gather_counts(nbytes, dense.device, group)
+    assert len(counts) == world and counts[rank] == nbytes
+    res = None
     ops = []
     if rank == dst:
-        out = torch.empty(sum(counts), dtype=torch.uint8, device=dense.device)
+        total = sum(counts)
+        if out is None:
+            out = torch.empty(total, dtype=torch.uint8, device=dense.device)
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= total, "gather buffer too small"
+        res = out.view(-1)[:total]
         at = 0
         for r in range(world):
             if r == dst:
-                out[at:at + counts[r]].copy_(dense[:counts[r]])
-            elif counts[r]:
-                ops.append(dist.P2POp(dist.irecv, out[at:at + counts[r]], r, group))
+                res[at:at + counts[r]].copy_(dense[:counts[r]])
+            else:
+                for v in _pieces(res[at:at + counts[r]], piece):
+                    ops.append(dist.P2POp(dist.irecv, v, r, group))
             at += counts[r]
-    elif nbytes:
-        ops.append(dist.P2POp(dist.isend, dense[:nbytes].contiguous(), dst, group))
+    else:
+        for v in _pieces(dense[:nbytes], piece):
+            ops.append(dist.P2POp(dist.isend, v, dst, group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    return out, counts
+    return res, counts
 
 
 def gather_lengths(lens: torch.Tensor, dst: int = 0, group=None) -> Optional[torch.Tensor]:

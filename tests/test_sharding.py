@@ -60,6 +60,74 @@ def _worker(rank, world, port, nblocks, block_len, q):
         dist.destroy_process_group()
 
 
+def _job_worker(rank, world, port, nb, block_len, piece, q):
+    """The config-5 job (lzs_compression_amd/sharded_job.py, what bench.py --gpus N runs) under gloo:
+    CPU tensors, the oracle standing in for the compress kernel, numpy for the compaction."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lzs_compression_amd.sharded_job import ShardedCompressJob
+        O = oracle.oracle()
+        stride = (oracle.compressed_max(block_len) + 15) // 16 * 16
+        sharding.P2P_PIECE = piece                      # several pieces per shard, like 8 GiB in 1 GiB pieces
+
+        def compress(x, slots, lens):
+            out, out_len, _ = oracle.run_blocks(O, x.numpy(), threads=1)
+            slots.zero_()
+            slots[:, :out.shape[1]] = torch.from_numpy(out)
+            lens.copy_(torch.from_numpy(out_len.astype(np.int32)))
+
+        def compact(slots, lens, dense, offsets):
+            at = 0
+            for b in range(slots.shape[0]):
+                n = int(lens[b])
+                dense[at:at + n] = slots[b, :n]
+                offsets[b] = at
+                at += n
+            offsets[slots.shape[0]] = at
+            return at
+
+        job = ShardedCompressJob(nb, block_len, stride, torch.device("cpu"), compress, compact, lambda: None)
+        pieces = [torch.from_numpy(workload.fill("text", nb, block_len, first_block=r * nb)) for r in range(world)] if rank == 0 else None
+        for _ in range(2):                              # twice: buffers are reused from step to step
+            times = job.step(pieces)
+        assert set(times) == {"scatter", "compress", "gather", "total"}
+        mine = pieces[0] if rank == 0 else job.mine
+        assert np.array_equal(mine.numpy(), workload.fill("text", nb, block_len, first_block=rank * nb))
+        if rank == 0:
+            full = workload.fill("text", nb * world, block_len)
+            want_out, want_len, _ = oracle.run_blocks(O, full, threads=2)
+            want = np.concatenate([want_out[b, :want_len[b]] for b in range(nb * world)])
+            assert sum(job.counts) == len(want) and job.out.numel() == len(want)
+            assert np.array_equal(job.out.numpy(), want)
+            assert np.array_equal(job.all_lens.numpy().astype(np.uint32), want_len)
+        else:
+            assert job.out is None and job.all_lens is None
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover - surfaced by the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nb,block_len,piece", [(2, 5, 4096, 1 << 30), (8, 16, 512, 3000)])
+def test_config5_job_scatter_compress_gather_gloo(world, nb, block_len, piece):
+    """world 8 at config-5 proportions (16 tiny blocks per rank in place of 131072 x 64 KiB, shards
+    cut into several point-to-point pieces like 8 GiB into 1 GiB ones)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, nb, block_len, piece, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
 @pytest.mark.parametrize("world,nblocks", [(2, 11), (3, 7), (2, 1)])
 def test_scatter_compress_gather_gloo(world, nblocks):
     ctx = mp.get_context("spawn")
