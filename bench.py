@@ -192,9 +192,22 @@ def run_sharded(args, dist, rank: int, world: int, dev) -> None:
                          "algorithmic_bytes_per_launch": {"read_input": in_bytes, "total_read_plus_written": algo_bytes},
                          "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms))},
         }
-        print(json.dumps(result), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        emit(result)
+
+
+def emit(result: dict) -> None:
+    """The ONE JSON line, last on stdout: RCCL writes a version banner through C stdio, which a pipe
+    holds back until exit -- flush it out first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(result), flush=True)
 
 
 def main() -> None:
@@ -333,10 +346,11 @@ def main() -> None:
                 result["single_stream"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(host, lens_h, slots)
-        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit(result)
 
 
 if __name__ == "__main__":

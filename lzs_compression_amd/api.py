@@ -61,7 +61,7 @@ def lib() -> ctypes.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = ctypes.CDLL(_SO)
+        L = ctypes.CDLL(os.environ.get("LZS_LIBRARY", _SO))     # (LZS_LIBRARY: A/B builds during development)
         for name in ("lzs_compress", "lzs_decompress", "lzs_decompress_concat"):
             f = getattr(L, name)
             f.restype, f.argtypes = _sz, [_vp, _sz, _vp, _sz]

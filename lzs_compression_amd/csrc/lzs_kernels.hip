@@ -126,17 +126,23 @@ static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, u
                              uint32_t in_len, uint32_t nblocks, void *stream, uint32_t concat)
 {
     if (nblocks == 0) return 0;
-    const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
 #ifdef LZS_WITH_VARIANTS
-    static const int use_v1 = [] { const char *v = getenv("LZS_DECODER"); return v && v[0] == 'v' && v[1] == '1'; }();
-    if (use_v1) {
-        hipLaunchKernelGGL(lzs_decompress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
-                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
+    // A/B builds only: LZS_DECODER=v1|v2 select the wave-per-stream decoders of round 1
+    static const int older = [] { const char *v = getenv("LZS_DECODER"); return (v && v[0] == 'v') ? (v[1] == '1' ? 1 : (v[1] == '2' ? 2 : 0)) : 0; }();
+    if (older) {
+        const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
+        if (older == 1)
+            hipLaunchKernelGGL(lzs_decompress_blocks_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                               (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                               (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
+        else
+            hipLaunchKernelGGL(lzs_decompress_blocks_v2_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+                               (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                               (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(lzs_decompress_blocks_v2_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
+    hipLaunchKernelGGL(lzs_decompress_blocks_grp_kernel, dim3((nblocks + kDecGroups - 1) / kDecGroups), dim3(64), 0,
                        (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                        (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat);
     return (int)hipGetLastError();
