@@ -61,4 +61,4 @@ dist.destroy_process_group()
 print("ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    assert r.returncode == 0 and "ok" in r.stdout.split(), r.stderr[-2000:]      # (RCCL prints its version banner after it)
