@@ -28,6 +28,12 @@ int lzs_hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_memset(void *dst, int value, size_t bytes, void *stream);
 
+/* How CHAIN links the positions of a batch on the current device: 0 = by one ordered LDS exchange
+ * (the device was asked and applies same-address lanes in lane order), 1 = the order-independent
+ * form (the device failed the check, or LZS_CHAIN_FALLBACK=1).  The first call per device runs
+ * lzs_lds_order_check_kernel on `stream` and waits for it. */
+int lzs_hip_chain_mode(void *stream, int *mode);
+
 /* Kernel launches (asynchronous on `stream`). */
 int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                             const void *d_in, size_t in_stride, const uint32_t *d_in_len,

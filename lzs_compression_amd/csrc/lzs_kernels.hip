@@ -57,6 +57,8 @@ int lzs_hip_device_count(int *count) { return (int)hipGetDeviceCount(count); }
 
 const char *lzs_hip_strerror(int e) { return hipGetErrorString((hipError_t)e); }
 
+int lzs_hip_chain_mode(void *stream, int *mode);
+
 int lzs_hip_describe(char *buf, size_t cap)
 {
     int dev = 0;
@@ -65,10 +67,14 @@ int lzs_hip_describe(char *buf, size_t cap)
     hipDeviceProp_t p;
     e = hipGetDeviceProperties(&p, dev);
     if (e != hipSuccess) return (int)e;
-    snprintf(buf, cap, "hip device %d: %s (%s), %d CUs, %.0f GiB, LDS/CU %zu KiB; kernels: workgroup-per-block LZS compress, wave-per-stream decompress (gfx950)",
+    int mode = -1;
+    (void)lzs_hip_chain_mode(nullptr, &mode);
+    snprintf(buf, cap, "hip device %d: %s (%s), %d CUs, %.0f GiB, LDS/CU %zu KiB; kernels: workgroup-per-block LZS compress "
+                       "(chain build: %s), eight-streams-per-wavefront decompress (gfx950)",
              dev, p.name, p.gcnArchName, p.multiProcessorCount,
              (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0),
-             (size_t)p.maxSharedMemoryPerMultiProcessor / 1024);
+             (size_t)p.maxSharedMemoryPerMultiProcessor / 1024,
+             mode == 0 ? "ordered LDS exchange, verified on this device" : (mode == 1 ? "order-independent fallback" : "not checked"));
     return 0;
 }
 
@@ -90,11 +96,52 @@ int lzs_hip_memset(void *d, int v, size_t n, void *st)
     return n ? (int)hipMemsetAsync(d, v, n, (hipStream_t)st) : 0;
 }
 
+// 0: CHAIN by ordered LDS exchange (verified on this device), 1: the order-independent form.
+// Asked once per device: lzs_lds_order_check_kernel over 16384 conflict patterns (~0.1 ms); a device
+// that fails it -- or LZS_CHAIN_FALLBACK=1 -- gets the slower form, with a note on stderr.
+static int g_chain_mode[64];            // 0 = not asked yet, else mode + 1
+int lzs_hip_chain_mode(void *stream, int *mode)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) { *mode = 1; return 0; }
+    int m = __atomic_load_n(&g_chain_mode[dev], __ATOMIC_ACQUIRE);
+    if (m == 0) {
+        const char *force = getenv("LZS_CHAIN_FALLBACK");
+        if (force && force[0] && force[0] != '0') {
+            m = 2;
+        } else {
+            uint32_t *d_bad = nullptr, bad = 0;
+            e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+            if (e != hipSuccess) return (int)e;
+            e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), (hipStream_t)stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(lzs_lds_order_check_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, d_bad, 16384u);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+            (void)hipFree(d_bad);
+            if (e != hipSuccess) return (int)e;
+            m = bad ? 2 : 1;
+            if (bad)
+                fprintf(stderr, "liblzs: device %d does not apply same-address LDS exchanges of one instruction in lane order "
+                                "(%u lanes off in 16384 patterns): using the order-independent chain build (slower, same output)\n", dev, bad);
+        }
+        __atomic_store_n(&g_chain_mode[dev], m, __ATOMIC_RELEASE);
+    }
+    *mode = m - 1;
+    return 0;
+}
+
 int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                             const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                             uint32_t in_len, uint32_t nblocks, void *stream)
 {
     if (nblocks == 0) return 0;
+    int chain_mode = 0;
+    { const int e = lzs_hip_chain_mode(stream, &chain_mode); if (e) return e; }
 #ifdef LZS_WITH_VARIANTS
     const uint32_t grid = (nblocks + kWavesPerWG - 1) / kWavesPerWG;
     // A/B builds only: LZS_KERNEL=chain (one wave per block) | scan (brute force) select the earlier kernels
@@ -117,7 +164,7 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
 #endif
     hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0,
                        (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, (uint32_t)chain_mode);
     return (int)hipGetLastError();
 }
 
@@ -169,10 +216,12 @@ int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const vo
                                      void *stream)
 {
     if (nseg == 0) return 0;
+    int chain_mode = 0;
+    { const int e = lzs_hip_chain_mode(stream, &chain_mode); if (e) return e; }
     hipLaunchKernelGGL(lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
                        (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
                        d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
-                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open);
+                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open, (uint32_t)chain_mode);
     return (int)hipGetLastError();
 }
 
