@@ -8,7 +8,6 @@ import lzs_compression_amd as lzs
 from lzs_compression_amd import api, workload
 
 O = oracle.oracle()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 TRACE = os.environ.get("FUZZ_TRACE")
 
 
@@ -16,7 +15,6 @@ def stage(seed, name, **kw):
     if TRACE:
         print("stage", seed, name, kw, {k: os.environ.get(k) for k in ("LZS_STREAM_SEG", "LZS_DEC_SEG", "LZS_FORCE_STREAM")}, flush=True)
 
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 text = bytes(workload.fill("text", 16).reshape(-1))
 low = bytes(workload.fill("lowent", 16).reshape(-1))
 
@@ -129,14 +127,11 @@ def our_packets(rng, packets):
     return bytes(out)
 
 
-t0, it = time.time(), 0
-ONLY = os.environ.get("FUZZ_ONLY")
-while time.time() - t0 < budget:
-    seed = int(ONLY) if ONLY else seed0 * 100000 + it
-    if ONLY and it:
-        break
+def check_seed(seed):
+    """Every host-visible path on the inputs drawn from `seed`, against the oracle (and the compiled
+    reference where it is there); raises on the first difference and leaves the inputs in
+    gpurun_out/fuzz_fail_<seed>.pkl."""
     rng = random.Random(seed)
-    it += 1
     try:
         d = make(rng, rng.choice((3000, 60000, 400000, 1500000)))
         want = O.compress(d)
@@ -223,4 +218,17 @@ while time.time() - t0 < budget:
         pickle.dump(keep, open(os.path.join(os.path.dirname(__file__), "..", "..", "gpurun_out", "fuzz_fail_%d.pkl" % seed), "wb"))
         print("FAIL seed", seed, repr(e)[:300], {k: os.environ.get(k) for k in ("LZS_STREAM_SEG", "LZS_DEC_SEG", "LZS_FORCE_STREAM")}, flush=True)
         raise
-print(f"fuzz ok: {it} iterations in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, it = time.time(), 0
+    ONLY = os.environ.get("FUZZ_ONLY")
+    while time.time() - t0 < budget:
+        seed = int(ONLY) if ONLY else seed0 * 100000 + it
+        if ONLY and it:
+            break
+        it += 1
+        check_seed(seed)
+    print(f"fuzz ok: {it} iterations in {time.time() - t0:.0f} s (seeds {seed0 * 100000}..{seed0 * 100000 + it - 1})", flush=True)
