@@ -52,15 +52,33 @@ def usable_cores() -> int:
     return cores
 
 
+def kernel_identity() -> str:
+    """SHA-256 over the kernel sources (lzs_kernels.hip and kernels/*.inc, in name order): what a
+    counter measurement belongs to."""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "lzs_compression_amd", "csrc")
+    h = hashlib.sha256()
+    for f in [os.path.join(csrc, "lzs_kernels.hip")] + sorted(glob.glob(os.path.join(csrc, "kernels", "*.inc"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(cls: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None.
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/gpu_traffic.sh), or (None, why).  The file carries the identity of the kernel
+    sources it was measured on; with other sources in the tree the number is stale and not reported.
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide streaming reads."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        rec = json.load(open(path))[cls]
-        return {"hbm_bytes": rec["fetch_bytes_corrected"] + rec["write_bytes"], **rec}
+        doc = json.load(open(path))
+        rec = doc[cls]
     except (OSError, KeyError, ValueError):
-        return None
+        return None, "profiles/pmc_traffic.json has no entry for this class"
+    if doc.get("kernel_source_sha256") != kernel_identity():
+        return None, ("profiles/pmc_traffic.json was measured on other kernel sources (its kernel_source_sha256 differs "
+                      "from this tree's): stale, not reported; regenerate with tools/gpu_traffic.sh")
+    return {"hbm_bytes": rec["fetch_bytes_corrected"] + rec["write_bytes"], "kernel_source_sha256": doc["kernel_source_sha256"], **rec}, None
 
 
 def cpu_baseline(blocks_host: np.ndarray, gpu_len: np.ndarray, gpu_slots) -> dict:
@@ -219,6 +237,7 @@ def main() -> None:
     ap.add_argument("--blocks", type=int, default=None,
                     help="64 KiB blocks per GPU (default: 16384 = 1 GiB at N = 1, 131072 = 8 GiB at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the secondary single_stream line (profiling runs)")
     ap.add_argument("--sharded-job", action="store_true",
                     help="run the N > 1 job (scatter / compress / gather over torch.distributed) even at N = 1: "
                          "exercises that code path with the nccl backend on a one-GPU box")
@@ -292,7 +311,7 @@ def main() -> None:
 
     if rank == 0:
         avg_ms = float(np.mean(kernel_ms))
-        traffic = pmc_traffic(args.workload) if nb == 16384 else None
+        traffic, traffic_note = pmc_traffic(args.workload) if nb == 16384 else (None, "the counters were taken at 16384 blocks per launch")
         in_bytes = nb * BLOCK
         algo_bytes = in_bytes + int(lens_h.sum()) + 4 * nb
         achieved = in_bytes / (avg_ms * 1e-3) / 1e9
@@ -316,14 +335,14 @@ def main() -> None:
                        "compression_ratio": ratio},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic,
+                         "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic if traffic else traffic_note,
                          "kernel": "lzs_compress_blocks_wg_kernel",
                          "algorithmic_bytes_per_launch": {"read_input": in_bytes,
                                                           "total_read_plus_written": algo_bytes},
                          "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
                          "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
         }
-        if world == 1:
+        if world == 1 and not args.no_single_stream:
             # secondary, outside the timed region: the same bytes as ONE stream through
             # lzs_compress_stream_device, wall clock around the synchronous call
             try:

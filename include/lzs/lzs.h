@@ -90,8 +90,7 @@ size_t lzs_decompress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_
  * (pieces of 16 KiB and more are spread over many wavefronts in both directions);
  * 512-byte pieces, the reference tools' habit, work: the compressor collects them in the block
  * up to 3 KiB before it asks the device (17 MB/s), the decompressor runs at ~4 MB/s on them.
- * lzs_simple_compress_incremental (a low-RAM variant with the same output) is not
- * provided.  Without a HIP device: status = LZS_x_STATUS_ERROR, nothing consumed.
+ * Without a HIP device: status = LZS_x_STATUS_ERROR, nothing consumed.
  * ------------------------------------------------------------------------- */
 #define LZS_COMPRESS_HISTORY_SIZE   (LZS_MAX_HISTORY_SIZE + LZS_MAX_LOOK_AHEAD_LEN)
 #define LZS_DECOMPRESS_HISTORY_SIZE LZS_MAX_HISTORY_SIZE
@@ -159,6 +158,29 @@ static inline void lzs_compress_init(LzsCompressParameters_t * pParams) { lzs_co
  * Returns the number of bytes written to outPtr.
  */
 size_t lzs_compress_incremental(LzsCompressParameters_t * pParams, bool add_end_marker);
+
+/*
+ * The reference's low-memory compressor (lzs-compression-simple.c; lzs.h:136-166, 224-227): the same
+ * stream from a parameter block of 2112 bytes.  Here it is the same device code as above behind
+ * the smaller block: there is no room in it to collect small pieces or to park output, so every
+ * call that can decide a token reaches the device (~0.1 ms), and a call only takes the input whose
+ * worst-case output fits outLength -- give it at least 26 bytes of room, or it returns
+ * NO_OUTPUT_BUFFER_SPACE without progress.  lzs_simple_compress() is lzs_compress().
+ */
+typedef struct
+{
+    const uint8_t     * inPtr;
+    uint8_t           * outPtr;
+    size_t              inLength;
+    size_t              outLength;
+    uint8_t             status;     /* LzsCompressStatus_t flags of the last call */
+    /* Private.  Sized like the reference's members (lzs.h:155-165). */
+    uint8_t             reserved_[2079];
+} LzsSimpleCompressParameters_t;
+
+size_t lzs_simple_compress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_t * a_pInData, size_t a_inLen);
+void lzs_simple_compress_init(LzsSimpleCompressParameters_t * pParams);
+size_t lzs_simple_compress_incremental(LzsSimpleCompressParameters_t * pParams, bool add_end_marker);
 
 /* reference lzs-decompression.c:420-428 */
 void lzs_decompress_init(LzsDecompressParameters_t * pParams);

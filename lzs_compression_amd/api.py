@@ -83,6 +83,9 @@ def lib() -> ctypes.CDLL:
             f = getattr(L, name)
             f.restype, f.argtypes = None, [_vp]
         L.lzs_compress_incremental.restype, L.lzs_compress_incremental.argtypes = _sz, [_vp, ctypes.c_bool]
+        L.lzs_simple_compress.restype, L.lzs_simple_compress.argtypes = _sz, [_vp, _sz, _vp, _sz]
+        L.lzs_simple_compress_init.restype, L.lzs_simple_compress_init.argtypes = None, [_vp]
+        L.lzs_simple_compress_incremental.restype, L.lzs_simple_compress_incremental.argtypes = _sz, [_vp, ctypes.c_bool]
         L.lzs_decompress_incremental.restype, L.lzs_decompress_incremental.argtypes = _sz, [_vp]
         _lib = L
     return _lib
@@ -286,6 +289,12 @@ class CompressParameters(ctypes.Structure):
                 ("status", ctypes.c_uint8), ("reserved_", ctypes.c_uint8 * 14399)]
 
 
+class SimpleCompressParameters(ctypes.Structure):
+    """LzsSimpleCompressParameters_t (reference c/src/liblzs/lzs.h:136-166): 2112 bytes."""
+    _fields_ = [("inPtr", _vp), ("outPtr", _vp), ("inLength", _sz), ("outLength", _sz),
+                ("status", ctypes.c_uint8), ("reserved_", ctypes.c_uint8 * 2079)]
+
+
 class DecompressParameters(ctypes.Structure):
     """LzsDecompressParameters_t (reference c/src/liblzs/lzs.h:180-211)."""
     _fields_ = [("inPtr", _vp), ("outPtr", _vp), ("inLength", _sz), ("outLength", _sz),
@@ -313,13 +322,21 @@ class _Incremental:
 class IncrementalCompressor(_Incremental):
     """lzs_compress_init() + lzs_compress_incremental() (reference lzs-compression.c:479-823)."""
 
-    def __init__(self):
-        self.params = CompressParameters()
-        lib().lzs_compress_init_full(ctypes.addressof(self.params))
+    def __init__(self, simple: bool = False):
+        """``simple``: the reference's low-memory block and lzs_simple_compress_incremental()
+        (lzs-compression-simple.c: same stream, 2112-byte block)."""
+        self.simple = simple
+        if simple:
+            self.params = SimpleCompressParameters()
+            lib().lzs_simple_compress_init(ctypes.addressof(self.params))
+        else:
+            self.params = CompressParameters()
+            lib().lzs_compress_init_full(ctypes.addressof(self.params))
 
     def step(self, data: bytes, out_space: int, add_end_marker: bool = False):
         """One call: returns (output bytes, input bytes consumed, status flags)."""
-        return self._call(lib().lzs_compress_incremental, data, out_space, add_end_marker)
+        fn = lib().lzs_simple_compress_incremental if self.simple else lib().lzs_compress_incremental
+        return self._call(fn, data, out_space, add_end_marker)
 
 
 class IncrementalDecompressor(_Incremental):
@@ -333,12 +350,12 @@ class IncrementalDecompressor(_Incremental):
         return self._call(lib().lzs_decompress_incremental, data, out_space)
 
 
-def incremental_compress(data: bytes, in_chunk: int, out_chunk: int) -> bytes:
+def incremental_compress(data: bytes, in_chunk: int, out_chunk: int, simple: bool = False) -> bytes:
     """``data`` through lzs_compress_incremental() the way the reference's file tool drives it
     (c/src/utils/lzs-compress.c:91-134): ``in_chunk`` bytes offered and ``out_chunk`` bytes of room
     per call, unread input offered again, add_end_marker once the input is used up, until the
     call reports END_MARKER.  Returns the whole stream."""
-    c, out, pos, piece, finish = IncrementalCompressor(), bytearray(), 0, b"", False
+    c, out, pos, piece, finish = IncrementalCompressor(simple), bytearray(), 0, b"", False
     status, calls = 0, 0
     while not (status & STATUS_END_MARKER):
         if not piece and not finish:
@@ -350,6 +367,6 @@ def incremental_compress(data: bytes, in_chunk: int, out_chunk: int) -> bytes:
         out += got
         piece = piece[used:]
         calls += 1
-        if calls > 16 * (len(data) // max(1, min(in_chunk, out_chunk)) + 64):
+        if calls > 32 * (len(data) // max(1, min(in_chunk, out_chunk)) + 64):
             raise LzsError(LZS_E_HIP, "lzs_compress_incremental makes no progress")
     return bytes(out)

@@ -293,7 +293,8 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
         size_t total_in = 0;
         for (size_t b = 0; b < nblocks; b++) total_in += in_len_each ? in_len_each[b] : in_len;
         if (nblocks <= BATCH_SEG_MAX_BLOCKS && total_in >= STREAM_DEC_MIN && total_in / nblocks >= 1024u &&
-            (unsigned long long)nblocks * d_out_stride <= BATCH_SEG_MAX_EXTENT) {
+            (unsigned long long)nblocks * d_out_stride <= BATCH_SEG_MAX_EXTENT &&
+            (unsigned long long)nblocks * d_in_stride < 0xF0000000ull) {      /* segment tables hold 32-bit input offsets */
             rc = batch_decompress_segments(st, stream, who, d_out, d_out_stride, cap32, out_len, (uint32_t *)d_len, d_in, d_in_stride,
                                            in_len_each, (uint32_t)in_len, nblocks);
             if (rc != LZS_OK) goto done;

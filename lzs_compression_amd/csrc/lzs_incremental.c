@@ -25,6 +25,15 @@ _Static_assert(sizeof(LzsDecompressParameters_t) == 2096, "size of the reference
 _Static_assert(sizeof(LzsCompressParameters_t) == 14432, "size of the reference's LzsCompressParameters_t");
 _Static_assert(DEC_PRIV_AT + sizeof(dec_priv_t) <= sizeof(LzsDecompressParameters_t), "private state fits");
 
+/* one line on stderr per thread and failure text, not one per call of a loop that keeps calling */
+static __thread char inc_noted[64];
+static void inc_failed_note(const char *who)
+{
+    if (strncmp(inc_noted, tls_error, sizeof(inc_noted) - 1) == 0 && inc_noted[0]) return;
+    memcpy(inc_noted, tls_error, sizeof(inc_noted) - 1); inc_noted[sizeof(inc_noted) - 1] = 0;
+    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+}
+
 void lzs_decompress_init(LzsDecompressParameters_t *p)
 {
     if (!p) return;
@@ -61,13 +70,18 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     lzs_dec_resume_t h;
     memset(&h, 0, sizeof(h));
     size_t wave_limit = (size_t)16 << 20;
+    /* how much input one pass of the many-wavefront path looks at: it scans ALL of it but decodes
+     * only up to the first end marker, so a buffer of concatenated streams (what lzs-compress
+     * writes with -b) would be scanned once per marker in full; starts small, doubles only while
+     * the pass before was used up to its end */
+    size_t big_limit = (size_t)1 << 20;
     for (;;) {
         /* A large piece first goes to many wavefronts (stream_decompress) as far as
          * whole segments can be decoded; what is left -- the segment with the end marker, the
          * unfinished token at the end of the input, the last bytes before the output is full, a
          * copy still running -- is the one wavefront's below. */
         if (pv->rem == 0 && p->inLength >= INC_DEC_STREAM_MIN && p->outLength >= 4096u && !getenv("LZS_ONE_WAVE")) {
-            const size_t big = p->inLength < ((size_t)256 << 20) ? p->inLength : ((size_t)256 << 20);
+            const size_t big = p->inLength < big_limit ? p->inLength : big_limit;
             const uint32_t nb = (pv->qlen + 7u) / 8u;
             uint8_t pre[4] = {0, 0, 0, 0};
             const uint32_t v = pv->qlen ? pv->bitq >> (32u - pv->qlen) : 0u;     /* the queued bits, right-aligned */
@@ -80,7 +94,7 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
             const size_t room = p->outLength < 0xE0000000u ? p->outLength : 0xE0000000u;
             int rc = LZS_OK;
             const size_t got = stream_decompress(p->outPtr, room, p->inPtr, nb + big, 0, &rc, 0, &dp);
-            if (rc != LZS_OK) { p->status = LZS_D_STATUS_ERROR; return made; }
+            if (rc != LZS_OK) goto failed_quiet;
             if (got != SIZE_MAX && dp.segs_done > 0) {
                 const size_t at = (size_t)dp.segs_done * dp.seg + ((dp.next_entry & 0xFFu) >> 3);   /* in prefix + input */
                 const uint32_t b = dp.next_entry & 7u;
@@ -103,6 +117,7 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
                     pv->hist_len = (uint16_t)(keep + got);
                 }
                 const size_t used = at - nb + (b ? 1u : 0u);
+                if (used + 4u * (size_t)dp.seg >= big && big_limit < ((size_t)256 << 20)) big_limit *= 2;
                 p->inPtr += used;  p->inLength -= used;
                 p->outPtr += got;  p->outLength -= got;
                 made += got;
@@ -176,21 +191,35 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     staging_trim(st);
     return made;
 
+failed_quiet:
+    if (0) {
 failed:
-    p->status = LZS_D_STATUS_ERROR;
-    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+        inc_failed_note(who);
+    }
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
+    /* Terminal also for a caller that never looks at the ERROR flag (the reference's tools loop
+     * until the input is used up and STARVED is reported: utils/lzs-decompress.c:82-121): the
+     * input is dropped, so such a loop runs out instead of spinning on the same bytes for ever. */
+    p->inPtr += p->inLength; p->inLength = 0;
+    p->status = LZS_D_STATUS_ERROR | LZS_D_STATUS_INPUT_STARVED | LZS_D_STATUS_INPUT_FINISHED;
     return made;
 }
 
 /* ---------------------------------------------------- incremental interface: compression */
 /* reference lzs-compression.c:479-823.  Between calls the caller's block holds, in place of the
- * reference's ring and hash tables: the last INC_HIST bytes already encoded (what the next
- * piece's chains are built from: lzs_compress_segments_kernel warms up over 2176 + 64 bytes
- * before its first token), the <= 15 bytes after them that wait for more look-ahead, the offset
- * of a long match still running, the bits of the last, partial output byte, and output that
- * found no room.  Every call encodes what the data so far decides, as one piece of the stream
- * on the device (stream_compress_piece). */
+ * reference's ring and hash tables: the last bytes already encoded (what the next piece's chains
+ * are built from: lzs_compress_segments_kernel warms up over the window before its first token),
+ * the <= 15 bytes after them that wait for more look-ahead, the offset of a long match still
+ * running, the bits of the last, partial output byte, and output that found no room.  Every call
+ * encodes what the data so far decides, as one piece of the stream on the device
+ * (stream_compress_piece).
+ *
+ * Two blocks share the code below (enc_core_t says where their members are): the reference's
+ * LzsCompressParameters_t (14432 bytes: room for 2304 bytes of history, 3600 of input collected
+ * before the device is asked, 8 KiB of output that found no room) and its
+ * LzsSimpleCompressParameters_t (2112 bytes: the window and the look-ahead, nothing else -- every
+ * call goes to the device, and input is only taken as far as its worst-case output fits the
+ * caller's buffer). */
 #define INC_HIST      2304u
 #define INC_CARRY_MAX 3600u         /* room for bytes not yet encoded ... */
 #define INC_ACCUM     3072u         /* ... small pieces are collected up to here before the device is asked */
@@ -209,6 +238,24 @@ typedef struct __attribute__((packed)) {
 #define ENC_PRIV_AT 40u
 _Static_assert(ENC_PRIV_AT + sizeof(enc_priv_t) <= sizeof(LzsCompressParameters_t), "private state fits");
 
+typedef struct __attribute__((packed)) {
+    uint16_t data_len;              /* history (<= 2047), then carry_len bytes not yet encoded (<= 15) */
+    uint16_t ext_off;
+    uint8_t  carry_len, bit_len, bit_val;
+    uint8_t  data[LZS_MAX_HISTORY_SIZE + INC_UNDECIDED];
+} simple_priv_t;
+#define SIMPLE_PRIV_AT 33u
+_Static_assert(sizeof(LzsSimpleCompressParameters_t) == 2112, "size of the reference's LzsSimpleCompressParameters_t");
+_Static_assert(SIMPLE_PRIV_AT + sizeof(simple_priv_t) <= sizeof(LzsSimpleCompressParameters_t), "private state fits");
+
+/* one parameter block as the shared code sees it */
+typedef struct {
+    const uint8_t **inPtr; uint8_t **outPtr; size_t *inLength, *outLength; uint8_t *status;
+    uint8_t *data; uint32_t hist_keep, accum;     /* history kept between calls; input collected up to here */
+    uint8_t *pend; uint32_t pend_cap;             /* output that found no room (NULL, 0: there is none) */
+    uint32_t data_len, carry_len, pend_pos, pend_len, ext_off, bit_len, bit_val, marker_waiting;
+} enc_core_t;
+
 void lzs_compress_init_full(LzsCompressParameters_t *p)
 {
     if (!p) return;
@@ -218,83 +265,92 @@ void lzs_compress_init_full(LzsCompressParameters_t *p)
 
 void lzs_compress_init_quick(LzsCompressParameters_t *p) { lzs_compress_init_full(p); }
 
-/* hand `len` bytes to the caller's buffer, what does not fit to pend[] (room was reserved) */
-static size_t inc_deliver(LzsCompressParameters_t *p, enc_priv_t *pv, const uint8_t *src, size_t len)
+void lzs_simple_compress_init(LzsSimpleCompressParameters_t *p)
 {
-    const size_t now = len < p->outLength ? len : p->outLength;
-    memcpy(p->outPtr, src, now);
-    p->outPtr += now; p->outLength -= now;
-    memcpy(pv->pend, src + now, len - now);
-    pv->pend_pos = 0; pv->pend_len = (uint32_t)(len - now);
+    if (!p) return;
+    p->status = LZS_C_STATUS_NONE;
+    memset(p->reserved_, 0, sizeof(p->reserved_));
+}
+
+/* hand `len` bytes to the caller's buffer, what does not fit to pend[] (room was reserved) */
+static size_t inc_deliver(enc_core_t *s, const uint8_t *src, size_t len)
+{
+    const size_t now = len < *s->outLength ? len : *s->outLength;
+    memcpy(*s->outPtr, src, now);
+    *s->outPtr += now; *s->outLength -= now;
+    if (len > now) memcpy(s->pend, src + now, len - now);
+    s->pend_pos = 0; s->pend_len = (uint32_t)(len - now);
     return now;
 }
 
-size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
+static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *who)
 {
-    const char *who = "lzs_compress_incremental";
-    if (!p) return 0;
-    enc_priv_t *pv = (enc_priv_t *)((uint8_t *)p + ENC_PRIV_AT);
     size_t made = 0;
     uint8_t *tmp = NULL;
-    p->status = LZS_C_STATUS_NONE;
+    *s->status = LZS_C_STATUS_NONE;
     tls_error[0] = 0;
-    if ((p->inLength && !p->inPtr) || (p->outLength && !p->outPtr) ||
-        pv->data_len > sizeof(pv->data) || pv->carry_len > pv->data_len || pv->pend_len > INC_PEND_MAX || pv->pend_pos > pv->pend_len) {
+    if ((*s->inLength && !*s->inPtr) || (*s->outLength && !*s->outPtr) ||
+        s->data_len > s->hist_keep + (s->accum > INC_UNDECIDED ? INC_CARRY_MAX : INC_UNDECIDED) || s->carry_len > s->data_len ||
+        s->pend_len > s->pend_cap || s->pend_pos > s->pend_len) {
         fail(LZS_E_ARG, "%s: NULL buffer or a parameter block that was not initialised", who);
-        p->status = LZS_C_STATUS_ERROR;
+        *s->status = LZS_C_STATUS_ERROR;
         return 0;
     }
     /* no device, no stream: say so at the first call, not when the collected input is flushed */
-    if (require_device() != LZS_OK) {
-        fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
-        p->status = LZS_C_STATUS_ERROR;
-        return 0;
-    }
+    if (require_device() != LZS_OK) goto failed;
     /* output still waiting from the call before goes first (:574-588) */
-    if (pv->pend_pos < pv->pend_len) {
-        const size_t have = pv->pend_len - pv->pend_pos;
-        const size_t now = have < p->outLength ? have : p->outLength;
-        memcpy(p->outPtr, pv->pend + pv->pend_pos, now);
-        p->outPtr += now; p->outLength -= now; pv->pend_pos += (uint32_t)now; made += now;
-        if (pv->pend_pos < pv->pend_len) {
-            p->status = LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
+    if (s->pend_pos < s->pend_len) {
+        const size_t have = s->pend_len - s->pend_pos;
+        const size_t now = have < *s->outLength ? have : *s->outLength;
+        memcpy(*s->outPtr, s->pend + s->pend_pos, now);
+        *s->outPtr += now; *s->outLength -= now; s->pend_pos += (uint32_t)now; made += now;
+        if (s->pend_pos < s->pend_len) {
+            *s->status = LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
             return made;
         }
-        pv->pend_pos = pv->pend_len = 0;
-        if (pv->marker_waiting) {
-            pv->marker_waiting = 0;
-            p->status = LZS_C_STATUS_END_MARKER | (p->inLength ? 0 : LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED);
+        s->pend_pos = s->pend_len = 0;
+        if (s->marker_waiting) {
+            s->marker_waiting = 0;
+            *s->status = LZS_C_STATUS_END_MARKER | (*s->inLength ? 0 : LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED);
             return made;
         }
     }
+    int starved_for_room = 0;
     for (;;) {
-        /* Take as much input as the room for its output allows: 9 bits a byte at worst, into the
+        /* Take as much input as the room for its output allows: 9 bits a byte at worst (what is
+         * waiting undecided included), 8 bytes for the partial byte and the end marker; into the
          * caller's buffer and then into pend[]; one piece is at most 1 GiB. */
-        const size_t room = (p->outLength < ((size_t)1 << 40) ? p->outLength : ((size_t)1 << 40)) + INC_PEND_MAX;
-        const size_t fits = (8u * room - 64u) / 9u - pv->carry_len;
-        size_t take = p->inLength < fits ? p->inLength : fits;
+        const size_t room = (*s->outLength < ((size_t)1 << 40) ? *s->outLength : ((size_t)1 << 40)) + s->pend_cap;
+        const size_t worst = 8u * room >= 64u ? (8u * room - 64u) / 9u : 0u;       /* input bytes whose output surely fits */
+        if (worst <= s->carry_len) {
+            /* (only without pend[]: the caller's buffer alone is too small to promise anything) */
+            starved_for_room = 1;
+            break;
+        }
+        const size_t fits = worst - s->carry_len;
+        size_t take = *s->inLength < fits ? *s->inLength : fits;
         if (take > ((size_t)1 << 30)) take = (size_t)1 << 30;
-        const int last = add_end_marker && take == p->inLength;
-        const size_t n = (size_t)pv->data_len + take;
-        const uint32_t c0 = pv->data_len - pv->carry_len;
-        if (!last && n - c0 <= INC_ACCUM) {
+        const int last = add_end_marker && take == *s->inLength;
+        const size_t n = (size_t)s->data_len + take;
+        const uint32_t c0 = s->data_len - s->carry_len;
+        if (!last && n - c0 <= s->accum) {
             /* Too little to decide the next token (:641-647) -- or just little: a call costs
              * ~0.12 ms whatever its size, so pieces like the reference tools' 512 bytes are
              * collected in the block until there are 3 KiB of them (or the stream is finished). */
-            memcpy(pv->data + pv->data_len, p->inPtr, take);
-            pv->data_len += (uint32_t)take; pv->carry_len += (uint32_t)take;
-            p->inPtr += take; p->inLength -= take;
+            memcpy(s->data + s->data_len, *s->inPtr, take);
+            s->data_len += (uint32_t)take; s->carry_len += (uint32_t)take;
+            *s->inPtr += take; *s->inLength -= take;
             break;
         }
         piece_t pc;
         memset(&pc, 0, sizeof(pc));
-        pc.prefix = pv->data; pc.prefix_len = pv->data_len;
-        pc.c0 = c0; pc.ext_off = pv->ext_off; pc.bit0 = pv->bit_len; pc.first = pv->bit_val; pc.last = last;
+        pc.prefix = s->data; pc.prefix_len = s->data_len;
+        pc.c0 = c0; pc.ext_off = s->ext_off; pc.bit0 = s->bit_len; pc.first = (uint8_t)s->bit_val; pc.last = last;
         const size_t cap = LZS_COMPRESSED_MAX(n - c0) + 16;
         tmp = (uint8_t *)malloc(cap);
         if (!tmp) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
         int rc = LZS_OK;
-        const size_t got = stream_compress_piece(tmp, cap, p->inPtr, n, 0, &rc, &pc);
+        const size_t got = stream_compress_piece(tmp, cap, *s->inPtr, n, 0, &rc, &pc);
         if (rc != LZS_OK) goto failed_quiet;
         const size_t whole = last ? got : (size_t)(pc.nbits / 8);
         if (whole > got || whole > room || pc.c_exit > n || pc.c_exit < c0 || (last ? pc.c_exit != n : n - pc.c_exit > INC_UNDECIDED)) {
@@ -302,41 +358,81 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
                  who, n, c0, got, (unsigned long long)pc.nbits, pc.c_exit, room);
             goto failed;
         }
-        made += inc_deliver(p, pv, tmp, whole);
-        pv->bit_len = last ? 0 : (uint8_t)(pc.nbits & 7u);
-        pv->bit_val = pv->bit_len ? (uint8_t)(tmp[whole] & (0xFF00u >> pv->bit_len)) : 0;
-        pv->ext_off = (uint16_t)pc.ext_exit;
+        made += inc_deliver(s, tmp, whole);
+        s->bit_len = last ? 0 : (uint32_t)(pc.nbits & 7u);
+        s->bit_val = s->bit_len ? (uint32_t)(tmp[whole] & (0xFF00u >> s->bit_len)) : 0;
+        s->ext_off = pc.ext_exit;
         free(tmp); tmp = NULL;
-        /* the new history and carry: bytes [c_exit - INC_HIST, n) of prefix + input */
+        /* the new history and carry: bytes [c_exit - hist_keep, n) of prefix + input */
         {
-            const size_t from = pc.c_exit > INC_HIST ? pc.c_exit - INC_HIST : 0;
+            const size_t from = pc.c_exit > s->hist_keep ? pc.c_exit - s->hist_keep : 0;
             uint8_t keep[INC_HIST + INC_UNDECIDED + 1u];
             size_t k = 0;
             for (size_t i = from; i < n; ) {
-                if (i < pv->data_len) { const size_t m = (pv->data_len < n ? pv->data_len : n) - i; memcpy(keep + k, pv->data + i, m); k += m; i += m; }
-                else { const size_t m = n - i; memcpy(keep + k, p->inPtr + (i - pv->data_len), m); k += m; i += m; }
+                if (i < s->data_len) { const size_t m = (s->data_len < n ? s->data_len : n) - i; memcpy(keep + k, s->data + i, m); k += m; i += m; }
+                else { const size_t m = n - i; memcpy(keep + k, *s->inPtr + (i - s->data_len), m); k += m; i += m; }
             }
-            memcpy(pv->data, keep, k);
-            pv->data_len = (uint32_t)k;
-            pv->carry_len = (uint32_t)(n - pc.c_exit);
+            memcpy(s->data, keep, k);
+            s->data_len = (uint32_t)k;
+            s->carry_len = (uint32_t)(n - pc.c_exit);
         }
-        p->inPtr += take; p->inLength -= take;
+        *s->inPtr += take; *s->inLength -= take;
         if (last) {
-            if (pv->pend_len) pv->marker_waiting = 1;
-            else p->status |= LZS_C_STATUS_END_MARKER;
+            if (s->pend_len) s->marker_waiting = 1;
+            else *s->status |= LZS_C_STATUS_END_MARKER;
             break;
         }
-        if (pv->pend_len || p->inLength == 0) break;
+        if (s->pend_len || *s->inLength == 0) break;
     }
-    if (pv->pend_len) p->status |= LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
-    if (p->inLength == 0) p->status |= LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED;
+    if (s->pend_len || starved_for_room) *s->status |= LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
+    if (*s->inLength == 0) *s->status |= LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED;
     return made;
 
 failed:
-    fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+    inc_failed_note(who);
 failed_quiet:
     free(tmp);
-    p->status = LZS_C_STATUS_ERROR;
+    /* Terminal also for a caller that never looks at the ERROR flag (the reference's tool loops
+     * until END_MARKER: utils/lzs-compress.c:91-134): the input is dropped and END_MARKER set
+     * next to ERROR, so such a loop ends instead of spinning on the same bytes for ever. */
+    *s->inPtr += *s->inLength; *s->inLength = 0;
+    *s->status = LZS_C_STATUS_ERROR | LZS_C_STATUS_END_MARKER | LZS_C_STATUS_INPUT_STARVED | LZS_C_STATUS_INPUT_FINISHED;
     return made;
 }
 
+size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
+{
+    if (!p) return 0;
+    enc_priv_t *pv = (enc_priv_t *)((uint8_t *)p + ENC_PRIV_AT);
+    enc_core_t s = { &p->inPtr, &p->outPtr, &p->inLength, &p->outLength, &p->status,
+                     pv->data, INC_HIST, INC_ACCUM, pv->pend, INC_PEND_MAX,
+                     pv->data_len, pv->carry_len, pv->pend_pos, pv->pend_len, pv->ext_off, pv->bit_len, pv->bit_val, pv->marker_waiting };
+    const size_t made = inc_compress_core(&s, add_end_marker, "lzs_compress_incremental");
+    pv->data_len = s.data_len; pv->carry_len = s.carry_len; pv->pend_pos = s.pend_pos; pv->pend_len = s.pend_len;
+    pv->ext_off = (uint16_t)s.ext_off; pv->bit_len = (uint8_t)s.bit_len; pv->bit_val = (uint8_t)s.bit_val;
+    pv->marker_waiting = (uint8_t)s.marker_waiting;
+    return made;
+}
+
+/* reference lzs-compression-simple.c: the low-memory compressor with the same output
+ * (lzs.h:224-227).  Same calls, same stream; the 2112-byte block has no room to collect input or
+ * to park output, so every call with >= 16 bytes to decide is a device call, and a call only takes
+ * the input whose worst-case output (9 bits a byte, plus 8 bytes) fits outLength: with less than
+ * 26 bytes of room nothing may be promised and the call returns NO_OUTPUT_BUFFER_SPACE at once. */
+size_t lzs_simple_compress_incremental(LzsSimpleCompressParameters_t *p, bool add_end_marker)
+{
+    if (!p) return 0;
+    simple_priv_t *pv = (simple_priv_t *)((uint8_t *)p + SIMPLE_PRIV_AT);
+    enc_core_t s = { &p->inPtr, &p->outPtr, &p->inLength, &p->outLength, &p->status,
+                     pv->data, LZS_MAX_HISTORY_SIZE, INC_UNDECIDED, NULL, 0,
+                     pv->data_len, pv->carry_len, 0, 0, pv->ext_off, pv->bit_len, pv->bit_val, 0 };
+    const size_t made = inc_compress_core(&s, add_end_marker, "lzs_simple_compress_incremental");
+    pv->data_len = (uint16_t)s.data_len; pv->carry_len = (uint8_t)s.carry_len;
+    pv->ext_off = (uint16_t)s.ext_off; pv->bit_len = (uint8_t)s.bit_len; pv->bit_val = (uint8_t)s.bit_val;
+    return made;
+}
+
+size_t lzs_simple_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
+{
+    return lzs_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+}

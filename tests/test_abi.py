@@ -124,6 +124,8 @@ int main(void) {
     printf("%zu %zu %zu %zu %zu %zu ", sizeof(LzsDecompressParameters_t), offsetof(LzsDecompressParameters_t, inPtr),
            offsetof(LzsDecompressParameters_t, outPtr), offsetof(LzsDecompressParameters_t, inLength),
            offsetof(LzsDecompressParameters_t, outLength), offsetof(LzsDecompressParameters_t, status));
+    printf("%zu %zu %zu ", sizeof(LzsSimpleCompressParameters_t), offsetof(LzsSimpleCompressParameters_t, outLength),
+           offsetof(LzsSimpleCompressParameters_t, status));
     printf("%d %d %d %d %d %d %d %d %d %d\n", LZS_C_STATUS_INPUT_STARVED, LZS_C_STATUS_INPUT_FINISHED, LZS_C_STATUS_END_MARKER,
            LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE, LZS_C_STATUS_ERROR, LZS_D_STATUS_INPUT_STARVED, LZS_D_STATUS_INPUT_FINISHED,
            LZS_D_STATUS_END_MARKER, LZS_D_STATUS_NO_OUTPUT_BUFFER_SPACE, LZS_D_STATUS_ERROR);
@@ -139,7 +141,7 @@ int main(void) {
         return subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
 
     ours = measure(f"{INC}/lzs")
-    assert ours == ["14432", "0", "8", "16", "24", "32", "2096", "0", "8", "16", "24", "32",
+    assert ours == ["14432", "0", "8", "16", "24", "32", "2096", "0", "8", "16", "24", "32", "2112", "24", "32",
                     "1", "2", "4", "8", "16", "1", "2", "4", "8", "16"]
     ref_inc = "/root/reference/c/src/liblzs"
     if os.path.exists(os.path.join(ref_inc, "lzs.h")):
@@ -160,8 +162,15 @@ def test_incremental_calls_fail_loudly_without_a_gpu():
     d = lzs.IncrementalDecompressor()
     with pytest.raises(lzs.LzsError):
         d.step(bytes.fromhex("30e07c3000"), 100)
-    # nothing was consumed, nothing written
-    assert d.params.inLength == 5 and d.params.outLength == 100
+    # nothing written; the input is dropped and STARVED reported next to ERROR, so that a caller who
+    # never looks at ERROR (the reference's tool loops: utils/lzs-decompress.c:82-121) runs out of
+    # input instead of calling for ever with the same bytes
+    assert d.params.inLength == 0 and d.params.outLength == 100
+    assert d.params.status == lzs.api.STATUS_ERROR | lzs.api.STATUS_INPUT_STARVED | lzs.api.STATUS_INPUT_FINISHED
+    c2 = lzs.IncrementalCompressor()
+    with pytest.raises(lzs.LzsError):
+        c2.step(b"x" * 5000, 100, False)
+    assert c2.params.inLength == 0 and c2.params.status & lzs.api.STATUS_END_MARKER and c2.params.status & lzs.api.STATUS_ERROR
     # ... except what needs no codec: an empty call on an empty queue is just "starved"
     assert lzs.IncrementalDecompressor().step(b"", 10) == (b"", 0, lzs.api.STATUS_INPUT_STARVED | lzs.api.STATUS_INPUT_FINISHED)
 
@@ -178,3 +187,19 @@ def test_product_does_not_reference_the_oracle():
     so = os.path.join(pkg, "liblzs.so")
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "oracle" not in needed
+
+
+def test_every_symbol_of_the_reference_library_is_exported():
+    """The library carries the reference's soname (liblzs.so.4), so a program linked against the
+    reference must find every function it may call: all ten of c/src/liblzs/lzs.h:218-232, the
+    lzs_simple_* trio included."""
+    so = os.path.join(ROOT, "lzs_compression_amd", "liblzs.so")
+    ours = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout.splitlines() if " T " in l}
+    want = {"lzs_compress", "lzs_compress_init_quick", "lzs_compress_init_full", "lzs_compress_incremental",
+            "lzs_simple_compress", "lzs_simple_compress_init", "lzs_simple_compress_incremental",
+            "lzs_decompress", "lzs_decompress_init", "lzs_decompress_incremental"}
+    assert want <= ours, want - ours
+    ref = os.path.join(ROOT, "oracle", "_ref", "liblzs_ref.so")
+    if os.path.exists(ref):
+        theirs = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", ref], capture_output=True, text=True, check=True).stdout.splitlines() if " T " in l and "lzs_" in l}
+        assert theirs <= ours, theirs - ours

@@ -166,6 +166,43 @@ def test_smoke_pattern_50_in_100_out():
     assert out + rest == comp
 
 
+def test_simple_compressor_block_gives_the_same_stream():
+    """lzs_simple_compress / lzs_simple_compress_init / lzs_simple_compress_incremental
+    (reference lzs.h:224-227, lzs-compression-simple.c): same output as the hashed compressor
+    (SURVEY [probe]); here the same device code behind the 2112-byte block."""
+    comp, plain = golden_bytes("kat_compressed_1.bin"), golden_bytes("kat_decompressed_1.bin")
+    dst = ctypes.create_string_buffer(1024)
+    n = lzs.lib().lzs_simple_compress(ctypes.addressof(dst), 1024, plain, len(plain))
+    assert dst.raw[:n] == comp
+    for ins, outs in ((len(plain), 1000), (50, 100), (10, 1000), (1000, 26), (1, 64), (512, 512)):
+        assert lzs.incremental_compress(plain, ins, outs, simple=True) == comp, (ins, outs)
+    assert lzs.incremental_compress(b"", 10, 100, simple=True) == bytes.fromhex("c000")
+    rng = random.Random(3)
+    for kind in ("text", "lowent", "random", "zeros"):
+        data = _sample(kind, 120000)
+        want = O.compress(data)
+        assert lzs.incremental_compress(data, 4096, 8192, simple=True) == want, kind
+        assert lzs.incremental_compress(data, 100000, 200000, simple=True) == want, kind
+        # random pieces; room never below what the block can promise for
+        c, out, pos, pending, fin, status = lzs.IncrementalCompressor(simple=True), bytearray(), 0, b"", False, 0
+        for _ in range(200000):
+            if not pending and not fin and pos < len(data):
+                pending = data[pos:pos + rng.randint(1, 3000)]
+                pos += len(pending)
+            if not pending and pos >= len(data):
+                fin = True
+            got, used, status = c.step(pending, rng.randint(26, 4000), fin)
+            out += got
+            pending = pending[used:]
+            if status & api.STATUS_END_MARKER:
+                break
+        assert bytes(out) == want, kind
+    # too little room to promise anything: no progress, and it says so
+    c = lzs.IncrementalCompressor(simple=True)
+    got, used, status = c.step(plain, 20, False)
+    assert got == b"" and used == 0 and status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
+
+
 @pytest.mark.parametrize("data,hexout", [
     (b"", "c000"), (b"a", "30e000"), (b"aa", "30987000"), (b"a" * 9, "30e07c3000"),
     (b"a" * 24, "30e07fc300"), (b"abcXabcYabc", "30988c658c2259c23800"),
