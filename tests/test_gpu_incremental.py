@@ -4,6 +4,7 @@ GPU, driven through the C-ABI with the reference's own calling patterns
 (c/src/test/test-lzs-decompression.c:130-290, c/src/utils/lzs-compress.c:91-134,
 lzs-decompress.c:82-121).  Whatever the chunking, the stream is the one-shot stream, bit for bit.
 """
+import ctypes
 import os
 import random
 import subprocess
@@ -199,8 +200,17 @@ def test_simple_compressor_block_gives_the_same_stream():
         assert bytes(out) == want, kind
     # too little room to promise anything: no progress, and it says so
     c = lzs.IncrementalCompressor(simple=True)
-    got, used, status = c.step(plain, 20, False)
+    got, used, status = c.step(plain, 20, False)            # takes the 10 bytes whose output would fit, into the look-ahead
+    assert got == b"" and used == 10 and not status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
+    got, used, status = c.step(plain[10:], 20, False)
     assert got == b"" and used == 0 and status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
+    out, pending, fin = bytearray(), plain[10:], False       # with room it goes on from there
+    while not status & api.STATUS_END_MARKER:
+        got, used, status = c.step(pending, 100, fin)
+        out += got
+        pending = pending[used:]
+        fin = not pending
+    assert bytes(out) == comp
 
 
 @pytest.mark.parametrize("data,hexout", [
