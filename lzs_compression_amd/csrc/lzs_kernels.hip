@@ -251,6 +251,16 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
                                const uint32_t *d_seg_base, const uint32_t *d_seg_end, void *stream)
 {
     if (nseg == 0) return 0;
+    static const int old_scan = [] { const char *v = getenv("LZS_SCAN"); return v && v[0] == 'w'; }();   // LZS_SCAN=wave: A/B
+    if (!compare && d_all_ones && !old_scan) {
+        // the first round, every token of the stream: eight segments per wavefront (+ the all-0xFF flags)
+        hipLaunchKernelGGL(lzs_all_ones_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           (const uint8_t *)d_in, n, nseg, d_all_ones, seg, d_seg_base, d_seg_end);
+        hipLaunchKernelGGL(lzs_scan_stream_g8_kernel, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
+                           (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, seg,
+                           concat ? 1u : 0u, d_seg_base, d_seg_end);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_all_ones,
                        d_marks, compare ? 1u : 0u, seg, concat ? 1u : 0u, d_seg_base, d_seg_end);
