@@ -293,7 +293,7 @@ int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t tota
                                   uint32_t *d_left, void *stream)
 {
     if (total == 0) return 0;
-    uint32_t grid = (total + 255u) / 256u;
+    uint32_t grid = (total / 4u + 255u) / 256u + 1u;          // four bytes a thread
     if (grid > 65536u) grid = 65536u;
     hipLaunchKernelGGL(lzs_resolve_stream_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (uint8_t *)d_out, d_origin, total, round, d_left);
