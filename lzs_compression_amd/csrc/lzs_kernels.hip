@@ -276,7 +276,8 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
     if (nseg == 0) return 0;
     static const int old_decode = [] { const char *v = getenv("LZS_SEG_DECODE"); return v && v[0] == 'w'; }();   // LZS_SEG_DECODE=wave: A/B
     // streams that expand more than sixfold are runs: there one wavefront per segment wins (60 bytes a step)
-    if (!old_decode && (unsigned long long)cap <= 6ull * n) {
+    // (n == 0: a batch of blocks with segment tables -- the expansion is not known here)
+    if (!old_decode && (n == 0u || (unsigned long long)cap <= 6ull * n)) {
         hipLaunchKernelGGL(lzs_decode_stream_g8_kernel, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
                            (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
                            d_seg_base, d_seg_end, d_out_floor, d_out_limit);
