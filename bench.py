@@ -280,10 +280,7 @@ def main() -> None:
     def step():
         lzs.compress_blocks(x, None, cap, slots, lens)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def barrier():                   # (N = 1: no other rank to wait for)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -299,10 +296,6 @@ def main() -> None:
         ev[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     total_in = world * nb * BLOCK * args.steps
@@ -365,11 +358,7 @@ def main() -> None:
                 result["single_stream"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(host, lens_h, slots)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        emit(result)
+    emit(result)
 
 
 if __name__ == "__main__":

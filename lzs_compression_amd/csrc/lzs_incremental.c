@@ -191,11 +191,9 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     staging_trim(st);
     return made;
 
-failed_quiet:
-    if (0) {
 failed:
-        inc_failed_note(who);
-    }
+    inc_failed_note(who);
+failed_quiet:                       /* (stream_decompress has reported by itself) */
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
     /* Terminal also for a caller that never looks at the ERROR flag (the reference's tools loop
      * until the input is used up and STARVED is reported: utils/lzs-decompress.c:82-121): the
