@@ -87,7 +87,17 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
 int lzs_hip_launch_resolve_blocks(void *d_out, uint32_t *d_origin, size_t out_stride, const uint32_t *d_len,
                                   uint32_t nblocks, void *stream);   /* a batch: one workgroup per block, to the end */
 int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
-                                  uint32_t *d_left, void *stream);
+                                  uint32_t *d_left, int last /* expected to finish: finished groups keep their origins */,
+                                  void *stream);
+/* The rounds of the same on tails alone: the groups of four bytes in front of the starts
+ * d_seg_start[0], [stride], [2 stride] ... (positions in d_out) of `nseg` segments.  d_out must
+ * be 4-byte and d_origin 16-byte aligned. */
+int lzs_hip_launch_resolve_tails(void *d_out, uint32_t *d_origin, uint32_t total, const uint32_t *d_seg_start,
+                                 uint32_t nseg, uint32_t stride, uint32_t round, uint32_t *d_left, void *stream);
+/* Without rounds: a workgroup per `per_chunk` consecutive segments takes their tails in order;
+ * what is left open afterwards is a copy of a byte in the tail in front of its chunk. */
+int lzs_hip_launch_resolve_chunks(void *d_out, uint32_t *d_origin, uint32_t total, const uint32_t *d_seg_start,
+                                  uint32_t nseg, uint32_t per_chunk, uint32_t round, void *stream);
 /* The incremental entry points (lzs_incremental.c).  Status bits as in the reference's
  * LzsCompressStatus_t / LzsDecompressStatus_t (lzs.h:90-98, 168-176). */
 #define LZS_INC_INPUT_STARVED   0x01u

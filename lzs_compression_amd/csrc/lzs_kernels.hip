@@ -299,13 +299,31 @@ int lzs_hip_launch_resolve_blocks(void *d_out, uint32_t *d_origin, size_t out_st
 }
 
 int lzs_hip_launch_resolve_stream(void *d_out, uint32_t *d_origin, uint32_t total, uint32_t round,
-                                  uint32_t *d_left, void *stream)
+                                  uint32_t *d_left, int last, void *stream)
 {
     if (total == 0) return 0;
     uint32_t grid = (total / 4u + 255u) / 256u + 1u;          // four bytes a thread
     if (grid > 65536u) grid = 65536u;
     hipLaunchKernelGGL(lzs_resolve_stream_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (uint8_t *)d_out, d_origin, total, round, d_left);
+                       (uint8_t *)d_out, d_origin, total, round, d_left, last ? 1u : 0u);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_resolve_tails(void *d_out, uint32_t *d_origin, uint32_t total, const uint32_t *d_seg_start,
+                                 uint32_t nseg, uint32_t stride, uint32_t round, uint32_t *d_left, void *stream)
+{
+    if (total == 0 || nseg == 0 || stride == 0) return 0;
+    hipLaunchKernelGGL(lzs_resolve_tails_kernel, dim3((nseg + stride - 1u) / stride), dim3(256), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, d_origin, total, d_seg_start, stride, round, d_left);
+    return (int)hipGetLastError();
+}
+
+int lzs_hip_launch_resolve_chunks(void *d_out, uint32_t *d_origin, uint32_t total, const uint32_t *d_seg_start,
+                                  uint32_t nseg, uint32_t per_chunk, uint32_t round, void *stream)
+{
+    if (total == 0 || nseg < 2 || per_chunk == 0) return 0;
+    hipLaunchKernelGGL(lzs_resolve_chunks_kernel, dim3((nseg + per_chunk - 1u) / per_chunk), dim3(256), 0, (hipStream_t)stream,
+                       (uint8_t *)d_out, d_origin, total, d_seg_start, nseg, per_chunk, round);
     return (int)hipGetLastError();
 }
 

@@ -402,12 +402,34 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: %u bytes decoded in %.2f ms, %u with an origin in another segment\n", produce, t1 - t0, open[0]); t0 = t1; }
         uint32_t left = open[0];
-        for (uint32_t round = 1; left && round < 250; round++) {
+        /* All origins lie in the 2047 bytes in front of a segment start (the tails).  So: (1) a
+         * workgroup per chunk of consecutive segments settles their tails in order, up to copies
+         * of bytes in front of the chunk; (2) rounds of pointer jumping on the tails in front of
+         * the chunks alone; (3) one pass over everything.  (3) alone, repeated, does the job too:
+         * (1) and (2) are shortcuts, not conditions. */
+        const int aligned = ((uintptr_t)d_out & 3u) == 0 && ((uintptr_t)d_origin & 15u) == 0;
+        int tails = left && ndec > 1 && aligned && !getenv("LZS_NO_TAILS");
+        const int had_tails = tails;
+        uint32_t stride = 1, round = 1;
+        if (tails && ndec >= 64 && !getenv("LZS_NO_CHUNKS")) {
+            stride = (ndec + 2047u) / 2048u;                    /* <= 2048 workgroups: all resident at once */
+            if (stride < 16u) stride = 16u;
+            HIP_TRY(lzs_hip_launch_resolve_chunks(d_out, (uint32_t *)d_origin, before + produce, d_start, ndec, stride, round++, stream), who);
+            if (debug) { HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize"); t1 = now_ms(); fprintf(stderr, "liblzs stream decode: tails by chunks of %u segments in %.2f ms\n", stride, t1 - t0); t0 = t1; }
+        }
+        for (; left && round < 250; round++) {
             HIP_TRY(lzs_hip_memset(d_counters + 1, 0, 4, stream), "hipMemset");
-            HIP_TRY(lzs_hip_launch_resolve_stream(d_out, (uint32_t *)d_origin, before + produce, round, d_counters + 1, stream), who);
+            if (tails)
+                HIP_TRY(lzs_hip_launch_resolve_tails(d_out, (uint32_t *)d_origin, before + produce, d_start, ndec, stride, round, d_counters + 1, stream), who);
+            else
+                HIP_TRY(lzs_hip_launch_resolve_stream(d_out, (uint32_t *)d_origin, before + produce, round, d_counters + 1, had_tails, stream), who);
             HIP_TRY(lzs_hip_d2h(&left, d_counters + 1, 4, stream), "hipMemcpy D2H");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
-            if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: resolve round %u in %.2f ms, %u left\n", round, t1 - t0, left); t0 = t1; }
+            if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: resolve round %u (%s, stride %u) in %.2f ms, %u left\n", round, tails ? "tails" : "all", stride, t1 - t0, left); t0 = t1; }
+            if (tails && !left) {                               /* these tails are final: */
+                if (stride > 1) stride = 1; else tails = 0;     /* ... now all tails (one jump each), then everything else */
+                left = 1;
+            }
         }
         if (left) { fail(LZS_E_HIP, "%s: origins did not resolve", who); goto failed; }
         if (!dev) HIP_TRY(lzs_hip_d2h(out, (uint8_t *)d_out + before, produce, stream), "hipMemcpy D2H");
