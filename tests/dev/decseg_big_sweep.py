@@ -12,7 +12,7 @@ for cls in classes:
     buf, nbytes = lzs.compress_stream(x)
     comp = buf[:nbytes].clone()
     back = None
-    for seg in (4096, 8192, 12288, 16384, 24576, 32768, 65536):
+    for seg in [int(v) for v in os.environ.get("SEGS", "2048,3072,4096,6144,8192").split(",")]:
         os.environ["LZS_DEC_SEG"] = str(seg)
         best = 1e9
         for it in range(4):

@@ -452,6 +452,38 @@ def test_one_long_stream_on_many_workgroups_vs_oracle():
         assert lzs.compress(d, cut) == want[:cut]
 
 
+def test_stream_decompress_resolve_shortcuts_agree_with_plain_rounds(monkeypatch):
+    """How the copies across segment borders are settled after DECODE is a matter of
+    speed, not of result: tails by chunks of segments, pointer jumping on the tails alone, or plain
+    rounds over everything (LZS_NO_CHUNKS / LZS_NO_TAILS) give the plain text back -- on chains of
+    copies as long as the stream, on segments that produce less than a window (tails spanning
+    many of them) and far more than one, and at segment sizes from 256 bytes to 8 KiB."""
+    import torch
+    rng = np.random.default_rng(77)
+    text = bytes(workload.fill("text", 24).reshape(-1))
+    datas = [
+        text,                                                              # 1.5 MiB: words copied from copies of copies
+        bytes(workload.fill("lowent", 16).reshape(-1)),                    # a segment produces 25 x its size
+        bytes(workload.fill("random", 6).reshape(-1)),                     # a 256-byte segment produces ~228 bytes
+        (text[:1500] + bytes(rng.integers(0, 256, 700, dtype=np.uint8))) * 400,   # a period just over the window: copies 2200 back never, 1500 back always
+        bytes(rng.integers(0, 256, 1800, dtype=np.uint8)) * 700,           # one 1800-byte unit, copied on and on
+    ]
+    for d in datas:
+        comp = lzs.compress(d)
+        for seg in ("256", "1024", "8192"):
+            monkeypatch.setenv("LZS_DEC_SEG", seg)
+            monkeypatch.setenv("LZS_FORCE_STREAM", "1")
+            for off in ((), ("LZS_NO_CHUNKS",), ("LZS_NO_TAILS",)):
+                for name in ("LZS_NO_CHUNKS", "LZS_NO_TAILS"):
+                    monkeypatch.delenv(name, raising=False)
+                for name in off:
+                    monkeypatch.setenv(name, "1")
+                assert lzs.decompress(comp, len(d) + 8) == d, (len(d), seg, off)
+                x = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+                back, n = lzs.decompress_stream(x, len(d) + 16)
+                assert n == len(d) and back[:n].cpu().numpy().tobytes() == d, (len(d), seg, off, "device")
+
+
 def test_stream_device_entry_point_1gib_text():
     """lzs_compress_stream_device() at full size: 1 GiB of text as ONE stream (16384 segments).
     The oracle needs minutes for that, so the first 24 MiB of input are compressed by the oracle
