@@ -252,13 +252,23 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
 {
     if (nseg == 0) return 0;
     static const int old_scan = [] { const char *v = getenv("LZS_SCAN"); return v && v[0] == 'w'; }();   // LZS_SCAN=wave: A/B
-    if (!compare && d_all_ones && !old_scan) {
-        // the first round, every token of the stream: eight segments per wavefront (+ the all-0xFF flags)
-        hipLaunchKernelGGL(lzs_all_ones_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                           (const uint8_t *)d_in, n, nseg, d_all_ones, seg, d_seg_base, d_seg_end);
-        hipLaunchKernelGGL(lzs_scan_stream_g8_kernel, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
-                           (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, seg,
-                           concat ? 1u : 0u, d_seg_base, d_seg_end);
+    if (!old_scan && (d_all_ones || compare)) {
+        // a lane per segment; the first round with the all-0xFF flags, the later ones against its marks
+        static const int g8_scan = [] { const char *v = getenv("LZS_SCAN"); return v && v[0] == 'g'; }();   // LZS_SCAN=g8: A/B
+        if (d_all_ones)
+            hipLaunchKernelGGL(lzs_all_ones_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                               (const uint8_t *)d_in, n, nseg, d_all_ones, seg, d_seg_base, d_seg_end);
+        if (g8_scan)
+            hipLaunchKernelGGL(lzs_scan_stream_g8_kernel<8>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
+                               (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg,
+                               concat ? 1u : 0u, d_seg_base, d_seg_end);
+        else {
+            if (d_marks && !compare)     // no marks yet (one store per lane and mark otherwise: 128 scattered words a segment)
+                (void)hipMemsetAsync(d_marks, 0xFF, (size_t)nseg * kScanMarkWords * sizeof(uint32_t), (hipStream_t)stream);
+            hipLaunchKernelGGL(lzs_scan_stream_g8_kernel<1>, dim3((nseg + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                               (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg,
+                               concat ? 1u : 0u, d_seg_base, d_seg_end);
+        }
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,

@@ -225,7 +225,10 @@ int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len, con
     return rc;
 }
 
-/* Segment size for decompressing a stream of n compressed bytes: 8 KiB for long streams, smaller
+/* Segment size for decompressing a stream of n compressed bytes: 4 KiB for long streams (1 GiB of
+ * output, ms: text 53.7 / 51.8 / 53.9 at 2 / 4 / 8 KiB, high-entropy 56.1 / 51.8 / 51.1, low-entropy
+ * 8.1 / 9.7 / 11.2 -- smaller segments scan and decode a little faster, and since the copies across
+ * their borders are settled by chunks of segments their number costs little), smaller
  * for short ones so that they too are spread over many wavefronts (one wavefront decodes ~7 MB/s).
  * Measured (text, host buffers, ms; output size): 64 KiB 7.7 with one wavefront, 0.67 in 256-byte
  * segments; 256 KiB 30.8 / 1.0; 1 MiB 122.8 / 2.4 (6.3 in 8 KiB segments); 4 MiB 8.2 in 1 KiB
@@ -234,6 +237,7 @@ static uint32_t stream_dec_seg(size_t n)
 {
     const char *v = getenv("LZS_DEC_SEG");
     size_t seg = v ? strtoul(v, NULL, 10) : (n / 2048u + 255u) & ~(size_t)255u;
+    if (!v && seg > 4096u) seg = 4096u;
     const size_t most = lzs_hip_dec_segment_bytes();
     if (seg < 256u) seg = 256u;
     if (seg > most) seg = most;
