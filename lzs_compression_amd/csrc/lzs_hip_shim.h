@@ -80,7 +80,8 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
                                uint32_t seg, int concat /* go on after end markers */,
                                const uint32_t *d_seg_base, const uint32_t *d_seg_end /* or NULL, NULL */, void *stream);
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
-                                 const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
+                                 const void *d_in, uint32_t n, uint32_t in_extent /* readable bytes at d_in */,
+                                 uint32_t nseg, const uint32_t *d_entry,
                                  const uint32_t *d_out_start, uint32_t seg, int concat,
                                  const uint32_t *d_seg_base, const uint32_t *d_seg_end,
                                  const uint32_t *d_out_floor, const uint32_t *d_out_limit, void *stream);

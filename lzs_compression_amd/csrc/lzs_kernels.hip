@@ -278,7 +278,7 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
 }
 
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
-                                 const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
+                                 const void *d_in, uint32_t n, uint32_t in_extent, uint32_t nseg, const uint32_t *d_entry,
                                  const uint32_t *d_out_start, uint32_t seg, int concat,
                                  const uint32_t *d_seg_base, const uint32_t *d_seg_end,
                                  const uint32_t *d_out_floor, const uint32_t *d_out_limit, void *stream)
@@ -289,7 +289,7 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
     // (n == 0: a batch of blocks with segment tables -- the expansion is not known here)
     if (!old_decode && (n == 0u || (unsigned long long)cap <= 6ull * n)) {
         hipLaunchKernelGGL(lzs_decode_stream_g8_kernel, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
-                           (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
+                           (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
                            d_seg_base, d_seg_end, d_out_floor, d_out_limit);
         return (int)hipGetLastError();
     }

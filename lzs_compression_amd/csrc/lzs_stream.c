@@ -399,7 +399,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_start, start, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
-        HIP_TRY(lzs_hip_launch_decode_stream(d_out, before + produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n,
+        HIP_TRY(lzs_hip_launch_decode_stream(d_out, before + produce, (uint32_t *)d_origin, d_counters, d_in, (uint32_t)n, (uint32_t)n,
                                              ndec, d_entry, d_start, seg, concat, NULL, NULL, NULL, NULL, stream), who);
         uint32_t open[2] = {0, 0};
         HIP_TRY(lzs_hip_d2h(open, d_counters, 8, stream), "hipMemcpy D2H");
@@ -468,6 +468,11 @@ LZS_HIDDEN int batch_decompress_segments(staging_t *st, void *stream, const char
     size_t total_in = 0;
     for (size_t b = 0; b < nblocks; b++) total_in += in_len_each ? in_len_each[b] : in_len;
     const uint32_t seg = stream_dec_seg(total_in / 4);        /* (smaller than for one stream of that size: measured) */
+    uint32_t in_extent = 0;                                    /* the readable bytes at d_in: the kernels' loads are bounded by it */
+    for (size_t b = 0; b < nblocks; b++) {
+        const size_t to = b * d_in_stride + (in_len_each ? in_len_each[b] : in_len);
+        if (to > in_extent) in_extent = (uint32_t)to;
+    }
     uint32_t nseg = 0;
     for (size_t b = 0; b < nblocks; b++) nseg += ((in_len_each ? in_len_each[b] : in_len) + seg - 1) / seg;
     const uint32_t extent = (uint32_t)(nblocks * d_out_stride);
@@ -562,7 +567,7 @@ LZS_HIDDEN int batch_decompress_segments(staging_t *st, void *stream, const char
     HIP_TRY(lzs_hip_h2d(d_limit, limit, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
     HIP_TRY(lzs_hip_memset(d_counters, 0, 8, stream), "hipMemset");
     HIP_TRY(lzs_hip_memset(d_origin, 0xFF, 4 * (size_t)extent, stream), "hipMemset");      /* everything "clean" */
-    HIP_TRY(lzs_hip_launch_decode_stream(d_out, extent, (uint32_t *)d_origin, d_counters, d_in, 0, nseg, d_entry, d_start,
+    HIP_TRY(lzs_hip_launch_decode_stream(d_out, extent, (uint32_t *)d_origin, d_counters, d_in, 0, in_extent, nseg, d_entry, d_start,
                                          seg, 0, d_base, d_end, d_floor, d_limit, stream), who);
     {
         uint32_t open[2] = {0, 0};
