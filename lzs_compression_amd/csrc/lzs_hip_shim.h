@@ -24,6 +24,8 @@ int lzs_hip_free(void *p);
 int lzs_hip_stream_create(void **stream);
 int lzs_hip_stream_destroy(void *stream);
 int lzs_hip_stream_sync(void *stream);
+int lzs_hip_host_malloc(void **p, size_t bytes);      /* pinned host memory */
+int lzs_hip_host_free(void *p);
 int lzs_hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_memset(void *dst, int value, size_t bytes, void *stream);

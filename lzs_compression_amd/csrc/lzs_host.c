@@ -166,6 +166,7 @@ static void staging_destroy(void *p)
         if (st->buf[i]) lzs_hip_free(st->buf[i]);
     if (st->stream) lzs_hip_stream_destroy(st->stream);
     free(st->host_box);
+    if (st->host_tab) lzs_hip_host_free(st->host_tab);
     free(st);
 }
 
@@ -207,6 +208,17 @@ static size_t keep_max(void)
         limit = mb ? (size_t)mb << 20 : KEEP_MAX;
     }
     return limit;
+}
+
+LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes)
+{
+    if (st->host_tab_cap < bytes) {
+        if (st->host_tab) { lzs_hip_host_free(st->host_tab); st->host_tab = NULL; st->host_tab_cap = 0; }
+        const size_t want = (bytes + 65535u) & ~(size_t)65535u;
+        if (lzs_hip_host_malloc(&st->host_tab, want)) { st->host_tab = NULL; return NULL; }
+        st->host_tab_cap = want;
+    }
+    return st->host_tab;
 }
 
 LZS_HIDDEN void staging_trim(staging_t *st)

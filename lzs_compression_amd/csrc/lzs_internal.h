@@ -34,10 +34,13 @@ typedef struct {
     void  *buf[BUF_COUNT];
     size_t cap[BUF_COUNT];
     uint8_t *host_box;              /* host side of the small incremental calls' single copies */
+    void  *host_tab;                /* PINNED host memory for the per-segment tables of the stream paths: their */
+    size_t host_tab_cap;            /* copies are small and many (five a round), and pageable ones cost ~150 us each */
 } staging_t;
 LZS_HIDDEN staging_t *staging_get(void);
 LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **out);   /* 0 or a hipError_t */
 LZS_HIDDEN void staging_trim(staging_t *st);
+LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes);   /* grow-only, pinned; NULL: out of memory */
 LZS_HIDDEN double now_ms(void);
 
 /* thresholds of the one-shot calls */

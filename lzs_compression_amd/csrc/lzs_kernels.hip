@@ -80,6 +80,8 @@ int lzs_hip_describe(char *buf, size_t cap)
 
 int lzs_hip_malloc(void **p, size_t bytes) { return (int)hipMalloc(p, bytes ? bytes : 1); }
 int lzs_hip_free(void *p) { return (int)hipFree(p); }
+int lzs_hip_host_malloc(void **p, size_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault); }
+int lzs_hip_host_free(void *p) { return (int)hipHostFree(p); }
 int lzs_hip_stream_create(void **s) { return (int)hipStreamCreateWithFlags((hipStream_t *)s, hipStreamNonBlocking); }
 int lzs_hip_stream_destroy(void *s) { return (int)hipStreamDestroy((hipStream_t)s); }
 int lzs_hip_stream_sync(void *s) { return (int)hipStreamSynchronize((hipStream_t)s); }

@@ -69,13 +69,11 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
     if (require_device() != LZS_OK) goto failed;
     staging_t *st = staging_get();
     if (!st) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
-    entry = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    exitp = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    nbits = (uint64_t *)malloc(sizeof(uint64_t) * nseg);
-    bitat = (uint64_t *)malloc(sizeof(uint64_t) * nseg);
-    dirty = (uint8_t *)malloc(nseg);
-    openi = (uint32_t *)malloc(sizeof(uint32_t) * 2 * nseg);
-    if (!entry || !exitp || !nbits || !bitat || !dirty || !openi) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+    /* the per-segment tables, in pinned memory (they travel every round) */
+    nbits = (uint64_t *)staging_host_tables(st, ((size_t)nseg + 16u) * (2u * 8u + 4u * 4u + 1u));
+    if (!nbits) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+    bitat = nbits + nseg; entry = (uint32_t *)(bitat + nseg); exitp = entry + nseg; openi = exitp + nseg;
+    dirty = (uint8_t *)(openi + 2 * (size_t)nseg);
 
 #define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto failed; } } while (0)
     if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
@@ -202,7 +200,6 @@ failed:
     if (!dev) fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
 done:
-    free(entry); free(exitp); free(nbits); free(bitat); free(dirty); free(openi);
     { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
     if (status) *status = rc;
     return result;
@@ -270,14 +267,11 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
     if (require_device() != LZS_OK) goto failed;
     staging_t *st = staging_get();
     if (!st) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
-    ones = (uint8_t *)malloc(nseg);
-    seen = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    entry = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    exits = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    count = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    start = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
-    dirty = (uint8_t *)malloc(nseg);
-    if (!entry || !exits || !count || !start || !dirty || !ones || !seen) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+    /* the tables that travel every round, in pinned memory */
+    seen = (uint32_t *)staging_host_tables(st, ((size_t)nseg + 16u) * (5u * 4u + 2u));
+    if (!seen) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+    entry = seen + nseg; exits = entry + nseg; count = exits + nseg; start = count + nseg;
+    dirty = (uint8_t *)(start + nseg); ones = dirty + nseg;
 
 #define HIP_TRY(call, what) do { e = (call); if (e) { rc = hip_fail(e, what); goto failed; } } while (0)
     if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
@@ -449,7 +443,6 @@ failed:
     if (!dev) fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
     { staging_t *s2 = staging_get(); if (s2 && s2->stream) lzs_hip_stream_sync(s2->stream); }
 done:
-    free(entry); free(exits); free(count); free(start); free(dirty); free(ones); free(seen);
     { staging_t *s2 = staging_get(); if (s2) staging_trim(s2); }
     if (status) *status = rc;
     return result;
