@@ -452,6 +452,46 @@ def test_one_long_stream_on_many_workgroups_vs_oracle():
         assert lzs.compress(d, cut) == want[:cut]
 
 
+def test_block_decoder_input_feed_edges():
+    """The block decoder reads its input with buffer loads bounded by the end of the last stream of
+    a wavefront: streams at every byte alignment, lengths around the 16- and
+    128-byte chunk borders, the very last bytes of the allocation, and streams so far apart that
+    the launcher puts one on a wavefront (a 32-bit extent would not span eight)."""
+    import torch
+    rng = np.random.default_rng(5)
+    text = bytes(workload.fill("text", 2).reshape(-1))
+    plains = [text[:n] for n in (1, 2, 13, 14, 15, 16, 17, 100, 111, 112, 113, 127, 128, 129, 140, 141, 142, 143, 144, 145, 255, 256, 257, 1000, 4096, 65536)]
+    comps = [O.compress(p) for p in plains]
+    # (a) packed back to back at odd offsets, the last one ending exactly at the end of the tensor
+    for shift in range(0, 5):
+        stride = max(len(c) for c in comps) + shift                       # rows at every alignment as b * stride walks
+        stride += (stride % 2 == 0)                                       # odd stride: all four alignments occur
+        buf = np.zeros(((len(comps) - 1) * stride + len(comps[-1]),), dtype=np.uint8)
+        for b, c in enumerate(comps):
+            buf[b * stride: b * stride + len(c)] = np.frombuffer(c, dtype=np.uint8)
+        flat = torch.from_numpy(buf).cuda()
+        x = torch.as_strided(flat, (len(comps), len(comps[-1])), (stride, 1))
+        lens = torch.tensor([len(c) for c in comps], dtype=torch.int32, device="cuda")
+        out, out_len = lzs.decompress_blocks(x, lens, 65536)
+        torch.cuda.synchronize()
+        got_len = out_len.cpu().numpy()
+        out = out.cpu().numpy()
+        for b, p in enumerate(plains):
+            assert got_len[b] == len(p) and out[b, :len(p)].tobytes() == p, (shift, b, len(p))
+    # (b) far apart: 160 MB between streams, lengths on the device -> one stream per wavefront
+    far = 160 << 20
+    few = comps[-5:]
+    flat = torch.zeros(far * (len(few) - 1) + len(few[-1]), dtype=torch.uint8, device="cuda")
+    for b, c in enumerate(few):
+        flat[b * far: b * far + len(c)] = torch.from_numpy(np.frombuffer(c, dtype=np.uint8).copy()).cuda()
+    x = torch.as_strided(flat, (len(few), len(few[-1])), (far, 1))
+    lens = torch.tensor([len(c) for c in few], dtype=torch.int32, device="cuda")
+    out, out_len = lzs.decompress_blocks(x, lens, 65536)
+    torch.cuda.synchronize()
+    for b, p in enumerate(plains[-5:]):
+        assert int(out_len[b]) == len(p) and out[b, :len(p)].cpu().numpy().tobytes() == p, ("far", b)
+
+
 def test_stream_decompress_resolve_shortcuts_agree_with_plain_rounds(monkeypatch):
     """How the copies across segment borders are settled after DECODE is a matter of
     speed, not of result: tails by chunks of segments, pointer jumping on the tails alone, or plain
