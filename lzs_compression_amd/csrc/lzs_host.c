@@ -411,6 +411,13 @@ static size_t one_shot(const char *who, launch_fn launch, uint8_t *out, size_t c
         fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
         return 0;
     }
+    /* positions are 32-bit on the device: a stream that fills 4 GiB - 1 of a larger buffer may have
+     * more to give, and "full" would be a lie */
+    if (launch != lzs_hip_launch_compress && got == 0xFFFFFFFFu && useful > 0xFFFFFFFFull) {
+        fail(LZS_E_ARG, "%s: the stream expands to 4 GiB or more; decompress it in pieces (lzs_decompress_incremental)", who);
+        fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+        return 0;
+    }
     return got;
 }
 
