@@ -75,7 +75,7 @@ int lzs_hip_launch_extend_resume(void *d_out, uint32_t bit0, const void *d_in, u
  * d_out[d_out_limit[k]]. */
 #define LZS_SEG_STOP (1u << 30)
 unsigned lzs_hip_dec_segment_bytes(void);             /* the largest segment (long streams) */
-#define LZS_SCAN_MARK_WORDS 136u     /* per segment in d_marks: what a full walk leaves for repeated ones */
+#define LZS_SCAN_MARK_WORDS 140u     /* per segment in d_marks: what a full walk leaves for repeated ones */
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones /* or NULL */, uint32_t *d_marks, int compare,
