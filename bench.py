@@ -53,14 +53,15 @@ def usable_cores() -> int:
 
 
 def kernel_identity() -> str:
-    """SHA-256 over the kernel sources (lzs_kernels.hip and kernels/*.inc, in name order): what a
-    counter measurement belongs to."""
-    import glob
+    """SHA-256 over the sources the measured kernel, lzs_compress_blocks_wg_kernel, is compiled from
+    (kernels/common.inc and kernels/compress_wg.inc: its code, its LDS layout and its launch
+    geometry -- one workgroup of kWgThreads per block): what a counter measurement belongs to.
+    (The decoders' sources are not part of it: the traffic figure is the compress kernel's.)"""
     import hashlib
-    csrc = os.path.join(ROOT, "lzs_compression_amd", "csrc")
+    csrc = os.path.join(ROOT, "lzs_compression_amd", "csrc", "kernels")
     h = hashlib.sha256()
-    for f in [os.path.join(csrc, "lzs_kernels.hip")] + sorted(glob.glob(os.path.join(csrc, "kernels", "*.inc"))):
-        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    for name in ("common.inc", "compress_wg.inc"):
+        h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()
 
 
