@@ -19,9 +19,11 @@
 //                          of one long stream, their bit-level stitch, and the resume of a long
 //                          match for the incremental interface (3.5, 3.7)
 //   compress_variants.inc  "scan" and "chain", the earlier compressors (LZS_KERNEL=, A/B only)
-//   decompress_blocks.inc  one wavefront per stream, v2 default (3.3)
-//   decompress_stream.inc  one stream or a small batch on many wavefronts: scan, decode with
-//                          per-byte origins, resolve (3.6)
+//   decompress_blocks.inc  eight streams per wavefront (3.3); the earlier one-wavefront-per-stream
+//                          decoders for A/B builds
+//   decompress_stream.inc  one stream or a small batch on many wavefronts: scan (a lane per
+//                          segment), decode with per-byte origins (eight segments per wavefront),
+//                          origins resolved on the segments' tails by chunks, then everywhere (3.6)
 //   compact_resume.inc     slot compaction (3.4); the resumable decoder of the incremental
 //                          interface (3.7)
 // No MFMA anywhere: this is byte search and bit packing, not a contraction.
