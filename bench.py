@@ -336,6 +336,28 @@ def main() -> None:
                          "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
                          "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
         }
+        if world == 1:
+            # the box's own streaming figure next to the 8 TB/s of the data sheet (report
+            # the fraction against both): a device-to-device copy of the same 1 GiB, read + written
+            try:
+                y = torch.empty_like(x)
+                for _ in range(2):
+                    y.copy_(x)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(10):
+                    y.copy_(x)
+                c1.record()
+                torch.cuda.synchronize()
+                copy_gbps = 2.0 * x.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+                del y
+                result["roofline"]["measured_device_copy_GBps"] = copy_gbps
+                result["roofline"]["frac_of_measured_copy"] = result["roofline"]["total_GBps"] / copy_gbps
+                result["roofline"]["measured_copy_note"] = ("torch device-to-device copy of the input tensor, bytes read + written per second; "
+                                                             "frac_of_measured_copy = the kernel's read + written bytes per second over it")
+            except Exception as exc:                       # noqa: BLE001
+                result["roofline"]["measured_device_copy_GBps"] = None
+                result["roofline"]["measured_copy_note"] = f"copy measurement failed: {exc}"
         if world == 1 and not args.no_single_stream:
             # secondary, outside the timed region: the same bytes as ONE stream through
             # lzs_compress_stream_device, wall clock around the synchronous call
