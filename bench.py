@@ -334,6 +334,7 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": {"read_input": in_bytes,
                                                           "total_read_plus_written": algo_bytes},
                          "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
+                         "median_kernel_ms": float(np.median(kernel_ms)),
                          "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
         }
         if world == 1:
