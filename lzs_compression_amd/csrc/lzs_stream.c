@@ -424,10 +424,10 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
             HIP_TRY(lzs_hip_d2h(&left, d_counters + 1, 4, stream), "hipMemcpy D2H");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
             if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: resolve round %u (%s, stride %u) in %.2f ms, %u left\n", round, tails ? "tails" : "all", stride, t1 - t0, left); t0 = t1; }
-            if (tails && !left) {                               /* these tails are final: */
-                if (stride > 1) stride = 1; else tails = 0;     /* ... now all tails (one jump each), then everything else */
-                left = 1;
-            }
+            if (tails && !left) {                               /* the tails in front of the chunks are final: now everything */
+                tails = 0;                                      /* else -- a tail byte is one jump from its value, any other */
+                left = 1;                                       /* byte two (the pass stores no marks on what it finishes, so */
+            }                                                   /* a tail byte still shows its origin to whoever comes by) */
         }
         if (left) { fail(LZS_E_HIP, "%s: origins did not resolve", who); goto failed; }
         if (!dev) HIP_TRY(lzs_hip_d2h(out, (uint8_t *)d_out + before, produce, stream), "hipMemcpy D2H");
