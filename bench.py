@@ -3,40 +3,65 @@
 
 N = 1: a "step" is one pass of lzs_compress_batch_device over one batch of independent 64 KiB
 blocks already resident in HBM (BASELINE.json configs[1]: 1 GiB = 16384 blocks of
-enwik-style ASCII text).
+enwik-style ASCII text).  After the timed region EVERY block is compared with the reference C
+compressor on the host cores (which is also the cpu_baseline), and the config-5 job below is run
+once more at world size 1 (`config5_world1`), so that the scaling curve's first point has the same
+fields as the others.
 
 N > 1 (BASELINE.json configs[4]): 131072 blocks (8 GiB) per GPU --
 64 GiB at 8 GPUs -- generated in HBM on the root GPU by lzs_gen_blocks_kernel; a "step" is the
-whole job: SCATTER (root -> ranks, one batched group of RCCL point-to-point sends over xGMI),
-COMPRESS (every rank its shard; blocks are independent, no collective), GATHER (compaction +
-gather-v of the compressed streams and their lengths to the root).  `value` is the end-to-end
-rate of the whole job; the three phases are timed separately and the compute-only rate is
-reported next to it.  Weak scaling: per-GPU work is fixed.
+whole job, pipelined over chunks of blocks (lzs_compression_amd/sharded_job.py): SCATTER (root ->
+ranks, RCCL point-to-point over xGMI) || COMPRESS (every rank its shard; blocks are independent,
+no collective) || GATHER (compaction + gather-v of the compressed streams and their lengths to the
+root).  `value` is the end-to-end rate of the whole job; each phase is also timed alone, in one
+un-overlapped pass after the timed region (`phases_ms`, `compute_only_GBps`, `scatter_GBps`,
+`gather_GBps`).  Weak scaling: per-GPU work is fixed.
 
-    python bench.py                       # 1 GPU, text class
+How it starts (the parent never touches the GPU):
+
+    python bench.py                            # 1 GPU, in this process
+    python bench.py --gpus 8                   # no WORLD_SIZE in the environment: launches its own
+                                               # 8 ranks (a child `python -m torch.distributed.run`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 2
+        --master-port 29500 bench.py --gpus 8  # the driver's way: every rank is a supervisor that
+                                               # runs the job in a child process
+
+If the RCCL job fails or hangs on any rank (first hardware run of the point-to-point legs), every
+supervisor falls back to independent shards without any collective -- the compute-only
+weak-scaling number, labelled as such (`fallback`) -- so an 8-GPU lease never ends with no number.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import lzs_compression_amd as lzs          # noqa: E402
-from lzs_compression_amd import workload   # noqa: E402
-
 BLOCK = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level table)
+METRIC = "input GB/s on 64KiB blocks, bit-exact vs C ref"
+CLASS_NAMES = ("text", "lowent", "random")
+
+np = torch = lzs = workload = None
+
+
+def heavy_imports() -> None:
+    """numpy / torch / the library: only in processes that do GPU work (never in a launcher or a
+    supervisor, which must stay clean of the GPU so that they may start other programs)."""
+    global np, torch, lzs, workload
+    if lzs is None:
+        import numpy as _np
+        import torch as _torch
+        import lzs_compression_amd as _lzs
+        from lzs_compression_amd import workload as _workload
+        np, torch, lzs, workload = _np, _torch, _lzs, _workload
+        assert tuple(workload.CLASS_NAMES) == CLASS_NAMES
 
 
 def usable_cores() -> int:
@@ -82,54 +107,271 @@ def pmc_traffic(cls: str):
     return {"hbm_bytes": rec["fetch_bytes_corrected"] + rec["write_bytes"], "kernel_source_sha256": doc["kernel_source_sha256"], **rec}, None
 
 
-def cpu_baseline(blocks_host: np.ndarray, gpu_len: np.ndarray, gpu_slots) -> dict:
-    """The reference C compressor (oracle/_ref, kind "reference") or, where it did not
-    travel, our C restatement (kind "port"), one block per task on the host cores, on a
-    bounded sample of the same workload.  Also cross-checks the GPU output on that sample."""
+def cpu_baseline(blocks_host, gpu_len, gpu_slots) -> dict:
+    """The reference C compressor (oracle/_ref, kind "reference") or, where it did not travel, our C
+    restatement (kind "port"), one block per task on the host cores.  The TIMED sample is bounded
+    (about 15 core-seconds); the CHECK is not: every block of the launch is compressed on the host
+    and compared with the GPU's output, length and bytes (SURVEY.md 8d "every block compared")."""
+    import hashlib
     import oracle
     cores = usable_cores()
     kind = "reference" if oracle.have_ref() else "port"
     codec = oracle.ref() if kind == "reference" else oracle.oracle()
-    # size the sample for roughly 15 core-seconds of work: probe 64 blocks on one thread first
+    nb = len(blocks_host)
+    # size the timed sample for roughly 15 core-seconds of work: probe 64 blocks on one thread first
     _, _, probe = oracle.run_blocks(codec, blocks_host[:64], threads=1)
     per_block = max(probe / 64.0, 1e-6)
-    nsample = int(min(len(blocks_host), max(256, 15.0 / per_block)))
+    nsample = int(min(nb, max(256, 15.0 / per_block)))
     out, out_len, secs = oracle.run_blocks(codec, blocks_host[:nsample], threads=cores)
     _, _, secs1 = oracle.run_blocks(codec, blocks_host[:max(64, nsample // cores)], threads=1)
     one_core = max(64, nsample // cores) * BLOCK / secs1 / 1e9
-    exact = bool((out_len == gpu_len[:nsample]).all())
-    if exact:
-        g = gpu_slots[:nsample].cpu().numpy()
-        for b in range(0, nsample, max(1, nsample // 64)):
-            exact = exact and g[b, :out_len[b]].tobytes() == out[b, :out_len[b]].tobytes()
+    # ---- the check: all nb blocks, in pieces of 2048 (host memory stays small)
+    t_chk = time.perf_counter()
+    exact, first_bad, compared = True, None, 0
+    h_gpu, h_cpu = hashlib.sha256(), hashlib.sha256()
+    for lo in range(0, nb, 2048):
+        hi = min(nb, lo + 2048)
+        if hi <= nsample:
+            o, ol = out[lo:hi], out_len[lo:hi]
+        else:
+            o, ol, _ = oracle.run_blocks(codec, blocks_host[lo:hi], threads=cores)
+        g = gpu_slots[lo:hi].cpu().numpy()
+        gl = gpu_len[lo:hi]
+        same_len = bool((ol == gl).all())
+        for b in range(hi - lo):
+            n = int(ol[b])
+            gb, cb = g[b, :int(gl[b])], o[b, :n]
+            h_gpu.update(gb.tobytes())
+            h_cpu.update(cb.tobytes())
+            if exact and (int(gl[b]) != n or not np.array_equal(gb, cb)):
+                exact, first_bad = False, lo + b
+        exact = exact and same_len
+        compared += hi - lo
+    exact = exact and h_gpu.digest() == h_cpu.digest()
     return {"value": nsample * BLOCK / secs / 1e9, "unit": "GB/s", "cores": cores, "kind": kind,
             "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity/cgroup quota)",
             "one_core_GBps": one_core,
             "sample": f"first {nsample} of the same 64 KiB blocks ({nsample * BLOCK >> 20} MiB), "
                       f"one block per task, {cores} threads",
-            "gpu_output_bit_exact_on_sample": exact}
+            "gpu_output_bit_exact_on_sample": exact,
+            "check": {"blocks_compared": compared, "of": nb, "what": "length and every byte of every block against the host codec",
+                      "sha256_of_all_streams": h_gpu.hexdigest(), "first_differing_block": first_bad,
+                      "seconds": time.perf_counter() - t_chk}}
 
 
-def run_sharded(args, dist, rank: int, world: int, dev) -> None:
-    """N > 1: the config-5 job (lzs_compression_amd/sharded_job.py), K timed passes."""
-    from lzs_compression_amd.sharded_job import ShardedCompressJob
-    nb = args.blocks if args.blocks is not None else 131072
+def emit(result: dict) -> None:
+    """The ONE JSON line, last on stdout: RCCL writes a version banner through C stdio, which a pipe
+    holds back until exit -- flush it out first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(result), flush=True)
+
+
+# ============================================================================ launching (no GPU here)
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="text", choices=CLASS_NAMES)
+    ap.add_argument("--blocks", type=int, default=None,
+                    help="64 KiB blocks per GPU (default: 16384 = 1 GiB at N = 1, 131072 = 8 GiB at N > 1)")
+    ap.add_argument("--chunk-blocks", type=int, default=8192,
+                    help="N > 1: blocks per pipeline chunk of the scatter || compress || gather job (default 8192 = 512 MiB)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: run the job un-overlapped (one chunk = the whole shard)")
+    ap.add_argument("--check-every", type=int, default=16,
+                    help="N > 1: the root compares the first 1/CHECK_EVERY and the last block of every chunk of every rank's "
+                         "gathered streams with the CPU oracle (1 = every block)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the secondary single_stream line (profiling runs)")
+    ap.add_argument("--no-config5", action="store_true", help="N = 1: skip the extra config5_world1 object (profiling runs)")
+    ap.add_argument("--sharded-job", action="store_true",
+                    help="run the N > 1 job (scatter / compress / gather over torch.distributed) even at N = 1: "
+                         "exercises that code path with the nccl backend on a one-GPU box")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="ranks may share a GPU (LOCAL_RANK modulo the device count): for testing the launch and "
+                         "fallback machinery on a one-GPU box; RCCL itself refuses two ranks on one device")
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def last_json_line(text: str):
+    for ln in reversed(text.strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                doc = json.loads(ln)
+            except ValueError:
+                continue
+            if "metric" in doc:
+                return ln
+    return None
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start N ranks ourselves, as a CHILD
+    process (torch.distributed.run), relay rank 0's JSON line, return its exit code."""
+    import tempfile
+    shared = tempfile.mkdtemp(prefix="lzs_bench_")
+    port = free_port()
+    env = dict(os.environ, LZS_BENCH_DIR=shared, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: no WORLD_SIZE in the environment, launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    out_path = os.path.join(shared, "launch.stdout")
+    with open(out_path, "w+") as out:
+        try:
+            rc = subprocess.run(cmd, env=env, stdout=out, timeout=float(os.environ.get("LZS_BENCH_LAUNCH_DEADLINE", "3000"))).returncode
+        except subprocess.TimeoutExpired:
+            rc = 124
+        out.seek(0)
+        text = out.read()
+    line = last_json_line(text)
+    if line is None:
+        sys.stderr.write(text[-4000:])
+        print("bench.py: the ranks produced no JSON line", file=sys.stderr)
+        return rc or 1
+    print(line, flush=True)
+    return rc
+
+
+def supervise(args, argv) -> int:
+    """One of torch.distributed.run's ranks: run the RCCL job in a child process (so that a crash, a
+    hang or an RCCL abort there leaves this process alive and clean of the GPU); if it fails on ANY
+    rank, run the independent-shards fallback on EVERY rank.  Rank 0 relays the JSON line."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    shared = os.environ.get("LZS_BENCH_DIR") or os.path.join(
+        "/tmp", f"lzs_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+    os.makedirs(shared, exist_ok=True)
+    env = dict(os.environ, LZS_BENCH_DIR=shared)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    worker_cmd = os.environ.get("LZS_BENCH_WORKER_CMD")          # tests: a stand-in worker
+    cmd = (worker_cmd.split() if worker_cmd else [sys.executable, os.path.abspath(__file__)]) + list(argv)
+
+    def flag(name: str, text: str = "") -> None:
+        tmp = os.path.join(shared, f".{name}.tmp")
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, os.path.join(shared, name))
+
+    def flags(prefix: str):
+        return [n for n in os.listdir(shared) if n.startswith(prefix)]
+
+    def run_worker(role: str, deadline_s: float, watch_failures: bool):
+        out_path = os.path.join(shared, f"out.{role}.{rank}")
+        t_end = time.time() + deadline_s
+        with open(out_path, "w+") as out:
+            proc = subprocess.Popen(cmd, env=dict(env, LZS_BENCH_ROLE=role), stdout=out)
+            why, seen_fail_at = None, None
+            while proc.poll() is None:
+                time.sleep(0.2)
+                if watch_failures and seen_fail_at is None and flags("fail1."):
+                    seen_fail_at = time.time()
+                if seen_fail_at is not None and time.time() - seen_fail_at > 5.0:
+                    why = "another rank failed"
+                elif time.time() > t_end:
+                    why = f"no result after {deadline_s:.0f} s"
+                if why:
+                    proc.kill()                       # (this exact child)
+                    proc.wait()
+                    break
+            out.seek(0)
+            text = out.read()
+        rc = proc.returncode
+        return (rc if why is None else (rc or 1)), text, why
+
+    line, reason = None, None
+    ok = False
+    if os.environ.get("LZS_BENCH_FORCE_FALLBACK"):
+        reason = "LZS_BENCH_FORCE_FALLBACK is set"
+    else:
+        rc, text, why = run_worker("job", float(os.environ.get("LZS_BENCH_JOB_DEADLINE", "1500")), True)
+        line = last_json_line(text)
+        ok = rc == 0 and (rank != 0 or line is not None)
+        if not ok:
+            flag(f"fail1.{rank}", why or f"exit code {rc}")
+            print(f"bench.py: rank {rank}: the sharded job failed ({why or f'exit code {rc}'})", file=sys.stderr, flush=True)
+    # ---- agree on the outcome of the first attempt: every rank reports, any failure sends all to the fallback
+    flag(f"done1.{rank}", "ok" if ok else "fail")
+    t_end = time.time() + float(os.environ.get("LZS_BENCH_JOB_DEADLINE", "1500")) + 60
+    while len(flags("done1.")) < world and time.time() < t_end:
+        time.sleep(0.1)
+    failed = sorted(flags("fail1."))
+    everybody_ok = ok and not failed and len(flags("done1.")) == world
+    if not everybody_ok:
+        if reason is None:
+            notes = []
+            for n in failed[:3]:
+                try:
+                    notes.append(f"rank {n.split('.')[-1]}: {open(os.path.join(shared, n)).read().strip()}")
+                except OSError:
+                    pass
+            reason = "the RCCL scatter / compress / gather job failed (" + "; ".join(notes or ["a rank did not report"]) + ")"
+        flag("reason", reason)
+        rc, text, why = run_worker("independent", float(os.environ.get("LZS_BENCH_FALLBACK_DEADLINE", "900")), False)
+        line = last_json_line(text)
+        ok = rc == 0 and (rank != 0 or line is not None)
+        if not ok:
+            print(f"bench.py: rank {rank}: the fallback failed too ({why or f'exit code {rc}'})", file=sys.stderr, flush=True)
+            sys.stderr.write(text[-2000:])
+    if rank == 0 and line is not None:
+        print(line, flush=True)
+    return 0 if ok else 1
+
+
+# ============================================================================ workers (GPU)
+def pick_device(args):
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = torch.cuda.device_count()
+    if n == 0:
+        raise SystemExit("bench.py: no GPU visible (there is no CPU path)")
+    if local_rank >= n and not args.allow_shared_gpu:
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {n} GPU(s) visible (--allow-shared-gpu to share, for tests)")
+    torch.cuda.set_device(local_rank % n)
+    return torch.device("cuda", local_rank % n)
+
+
+def job_callbacks(kernel_ev):
+    """The two device operations the job is built around, as bench.py passes them to ShardedCompressJob."""
     cap = lzs.compressed_max(BLOCK)
-    slot_stride = (cap + 15) // 16 * 16
-    kernel_ev = []
 
     def compress(x, slots, lens):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         lzs.compress_blocks(x, None, cap, slots, lens)
         b.record()
-        kernel_ev.append((a, b))
+        kernel_ev.append((a, b, x.shape[0]))
 
     def compact(slots, lens, dense, offsets):
         lzs.compact(slots, lens, dense=dense, offsets=offsets)
-        return int(offsets[-1].item())
 
-    job = ShardedCompressJob(nb, BLOCK, slot_stride, dev, compress, compact, torch.cuda.synchronize)
+    return compress, compact
+
+
+def run_sharded(args, dist, rank: int, world: int, dev) -> dict:
+    """The config-5 job (lzs_compression_amd/sharded_job.py), K timed passes; returns the result on
+    rank 0 (None elsewhere)."""
+    from lzs_compression_amd.sharded_job import ShardedCompressJob
+    nb = args.blocks if args.blocks is not None else 131072
+    cap = lzs.compressed_max(BLOCK)
+    slot_stride = (cap + 15) // 16 * 16
+    cb = nb if args.no_overlap else min(nb, args.chunk_blocks)
+    kernel_ev = []
+    compress, compact = job_callbacks(kernel_ev)
+    job = ShardedCompressJob(nb, BLOCK, slot_stride, dev, compress, compact, torch.cuda.synchronize, chunk_blocks=cb)
     # ---- the root generates every rank's blocks in HBM, one piece (<= 8 GiB) per rank
     pieces = None
     t_gen = time.perf_counter()
@@ -148,130 +390,265 @@ def run_sharded(args, dist, rank: int, world: int, dev) -> None:
     kernel_ev.clear()
     barrier()
     t0 = time.perf_counter()
-    phases = [job.step(pieces) for _ in range(args.steps)]
+    steps = [job.step(pieces) for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
-    # MAX over ranks of the job time and of every phase's mean
-    mean = {k: float(np.mean([p[k] for p in phases])) for k in ("scatter", "compress", "gather", "total")}
-    t = torch.tensor([elapsed, mean["scatter"], mean["compress"], mean["gather"], mean["total"]], dtype=torch.float64, device=dev)
+    kernel_ms = [a.elapsed_time(b) for a, b, _n in kernel_ev]
+    kernel_blocks = [n for _a, _b, n in kernel_ev]
+    stage_ms = job.last_stage_ms
+    # ---- every phase alone: one un-overlapped pass (outside the timed region), same results
+    serial = job.serial_phases(pieces)
+    barrier()
+    t = torch.tensor([elapsed, serial["scatter"], serial["compress"], serial["gather"], serial["total"],
+                      float(np.mean([s["comm_busy"] for s in steps])), float(np.mean([s["compute_busy"] for s in steps]))],
+                     dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, sc, co, ga, tot = (float(v) for v in t.tolist())
-    kernel_ms = [a.elapsed_time(b) for a, b in kernel_ev]
+    elapsed, sc, co, ga, tot, comm_busy, comp_busy = (float(v) for v in t.tolist())
 
-    # ---- checks outside the timed region: every rank decodes its own shard on the device ...
+    # ---- checks outside the timed region.  Every rank: chunk by chunk, compress again, decode on the device
+    # (== the input) and compact again (== the bytes the job kept and sent)
     x = pieces[0] if rank == 0 else job.mine
-    back, back_len = lzs.decompress_blocks(job.slots, job.lens, BLOCK)
-    ok = bool((back_len == BLOCK).all()) and torch.equal(back[:, :BLOCK], x)
-    del back
+    ok = True
+    chk_slots = torch.empty((job.cb, slot_stride), dtype=torch.uint8, device=dev)
+    chk_lens = torch.empty(job.cb, dtype=torch.int32, device=dev)
+    chk_dense = torch.empty(job.cb * slot_stride, dtype=torch.uint8, device=dev)
+    chk_off = torch.empty(job.cb + 1, dtype=torch.int64, device=dev)
+    for j in range(job.K):
+        lo, hi = job._chunk(j)
+        n = hi - lo
+        lzs.compress_blocks(x[lo:hi], None, cap, chk_slots[:n], chk_lens[:n])
+        back, back_len = lzs.decompress_blocks(chk_slots[:n], chk_lens[:n], BLOCK)
+        ok = ok and bool((back_len == BLOCK).all()) and torch.equal(back[:, :BLOCK], x[lo:hi])
+        del back
+        lzs.compact(chk_slots[:n], chk_lens[:n], dense=chk_dense, offsets=chk_off[:n + 1])
+        cnt = int(chk_off[n].item())
+        ok = ok and cnt == job.chunk_counts[j][rank] and torch.equal(chk_dense[:cnt], job._dense_chunk(j)[:cnt])
+        ok = ok and torch.equal(chk_lens[:n], job.lens[lo:hi])
+    del chk_slots, chk_dense
     okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)
     lens_h = job.lens.cpu().numpy()
+    result = None
     if rank == 0:
-        # ... and the root compares sampled blocks of EVERY rank's part of the gathered bytes with the
-        # CPU oracle (first, middle and last block of each shard), at the gathered offsets
+        # ... and the root compares its gathered bytes with the CPU oracle: of every chunk of every rank
+        # the first 1/check_every blocks (one contiguous range of the gathered stream) and the last block
         import oracle
         O = oracle.oracle()
+        cores = usable_cores()
         all_lens = job.all_lens.cpu().numpy().astype(np.int64)
         offs = np.concatenate([[0], np.cumsum(all_lens)])
         gathered_ok = int(offs[-1]) == sum(job.counts) == int(job.out.numel())
+        compared = 0
+        t_chk = time.perf_counter()
         for r in range(world):
-            for b in (0, nb // 2, nb - 1):
-                g = r * nb + b
-                got = bytes(job.out[int(offs[g]):int(offs[g + 1])].cpu().numpy())
-                gathered_ok = gathered_ok and got == O.compress(bytes(pieces[r][b].cpu().numpy()))
+            for j in range(job.K):
+                lo, hi = job._chunk(j)
+                m = max(1, (hi - lo + args.check_every - 1) // args.check_every)
+                for a, b in ((lo, lo + m), (hi - 1, hi)) if m < hi - lo else ((lo, hi),):
+                    rows = pieces[r][a:b].cpu().numpy()
+                    want, want_len, _ = oracle.run_blocks(O, rows, threads=cores)
+                    g0 = r * nb + a
+                    got = job.out[int(offs[g0]):int(offs[g0 + (b - a)])].cpu().numpy()
+                    gathered_ok = gathered_ok and bool((want_len == all_lens[g0:g0 + (b - a)]).all())
+                    if gathered_ok:
+                        cat = np.concatenate([want[i, :want_len[i]] for i in range(b - a)])
+                        gathered_ok = cat.size == got.size and bool(np.array_equal(cat, got))
+                    compared += b - a
+        t_chk = time.perf_counter() - t_chk
         total_in = world * nb * BLOCK
         in_bytes = nb * BLOCK
-        avg_ms = float(np.mean(kernel_ms))
-        achieved = in_bytes / (avg_ms * 1e-3) / 1e9
+        per_gib = [ms / (n * BLOCK / 2**30) for ms, n in zip(kernel_ms, kernel_blocks)]
+        avg_ms_per_gib = float(np.mean(per_gib))
+        achieved = 2**30 / (avg_ms_per_gib * 1e-3) / 1e9
         algo_bytes = in_bytes + int(lens_h.sum()) + 4 * nb
         result = {
-            "metric": "input GB/s on 64KiB blocks, bit-exact vs C ref",
+            "metric": METRIC,
             "value": total_in * args.steps / elapsed / 1e9,
             "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{world * nb} independent 64 KiB blocks ({world * nb * BLOCK >> 30} GiB / {world} GPUs), class "
+            "config": {"workload": f"{world * nb} independent 64 KiB blocks ({world * nb * BLOCK / 2**30:g} GiB / {world} GPUs), class "
                                    f"'{args.workload}', generated in HBM on the root GPU, scattered {nb} blocks "
-                                   f"({nb * BLOCK >> 30} GiB) per rank over RCCL/xGMI, compressed, compacted, gathered to the root",
+                                   f"({nb * BLOCK / 2**30:g} GiB) per rank over RCCL/xGMI, compressed, compacted, gathered to the root",
                        "class": args.workload, "blocks_per_gpu": nb, "block_bytes": BLOCK,
-                       "sharding": f"contiguous block ranges, {nb} per rank; a step = scatter + compress + gather",
+                       "sharding": f"contiguous block ranges, {nb} per rank; a step = the whole job: scatter || compress || gather, "
+                                   f"pipelined over chunks of {job.cb} blocks" if job.overlap else
+                                   f"contiguous block ranges, {nb} per rank; a step = scatter, then compress, then gather",
                        "compression_ratio": float(all_lens.sum()) / total_in},
-            "phases_ms": {"scatter": sc * 1e3, "compress": co * 1e3, "gather": ga * 1e3, "step": tot * 1e3,
-                          "note": "mean over the timed steps, MAX over ranks; each phase ends with a device synchronize"},
+            "overlap": bool(job.overlap), "chunk_blocks": job.cb, "chunks_per_rank": job.K,
             "end_to_end_GBps": total_in * args.steps / elapsed / 1e9,
+            "phases_ms": {"scatter": sc * 1e3, "compress": co * 1e3, "gather": ga * 1e3, "step": tot * 1e3,
+                          "note": "each phase ALONE: one un-overlapped pass of the same job after the timed steps, every phase "
+                                  "ended by a device synchronize, MAX over ranks; compress includes the compaction of the slots"},
+            "serial_end_to_end_GBps": total_in / tot / 1e9,
             "compute_only_GBps": total_in / co / 1e9,
-            "scatter_GBps": (world - 1) * nb * BLOCK / sc / 1e9 if sc > 0 else None,
-            "gather_GBps": (sum(job.counts) - job.counts[0]) / ga / 1e9 if ga > 0 else None,
+            "scatter_GBps": (world - 1) * nb * BLOCK / sc / 1e9 if sc > 0 and world > 1 else None,
+            "gather_GBps": (sum(job.counts) - job.counts[0]) / ga / 1e9 if ga > 0 and world > 1 else None,
+            "overlapped_step": {"comm_busy_ms": comm_busy * 1e3, "compute_busy_ms": comp_busy * 1e3,
+                                "stage_comm_ms_rank0_last_step": stage_ms.get("comm"), "stage_compute_ms_rank0_last_step": stage_ms.get("compute"),
+                                "note": "HIP events around every stage's batch of point-to-point operations (comm) and every "
+                                        "chunk's compress + compact (compute); busy = their sums, mean over steps, MAX over ranks"},
             "gathered_bytes": int(sum(job.counts)),
             "generate_on_root_s": t_gen,
-            "checks": {"every_rank_round_trip_on_device": bool(okt.item()), "gathered_samples_equal_oracle": bool(gathered_ok)},
+            "checks": {"every_rank_round_trip_on_device": bool(okt.item()), "gathered_samples_equal_oracle": bool(gathered_ok),
+                       "gathered_blocks_compared_with_oracle": compared, "of": world * nb, "oracle_check_s": t_chk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "lzs_compress_blocks_wg_kernel (rank 0's launches)",
-                         "algorithmic_bytes_per_launch": {"read_input": in_bytes, "total_read_plus_written": algo_bytes},
-                         "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms))},
+                         "kernel": "lzs_compress_blocks_wg_kernel (rank 0's launches, beside the RCCL transfers)",
+                         "algorithmic_bytes_per_GiB_launch": {"read_input": 2**30, "total_read_plus_written": algo_bytes * 2**30 // in_bytes},
+                         "avg_kernel_ms_per_GiB": avg_ms_per_gib, "launches": len(kernel_ms)},
         }
     dist.barrier()
+    return result
+
+
+def worker_job(args) -> int:
+    """Role "job": one rank of the RCCL job (child of a supervisor, or the process itself at world 1)."""
+    import datetime
+    heavy_imports()
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dev = pick_device(args)
+    # a collective that does not complete in 5 minutes aborts the process: the supervisor falls back
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+    result = run_sharded(args, dist, rank, world, dev)
     dist.destroy_process_group()
     if rank == 0:
         emit(result)
+    return 0
 
 
-def emit(result: dict) -> None:
-    """The ONE JSON line, last on stdout: RCCL writes a version banner through C stdio, which a pipe
-    holds back until exit -- flush it out first."""
-    import ctypes
-    sys.stdout.flush()
+def worker_independent(args) -> int:
+    """Role "independent" (the fallback): every rank compresses a shard of its own, generated on its own
+    GPU; NO collective, no RCCL -- ranks meet at a barrier made of files.  The compute-only
+    weak-scaling figure of round 1, labelled as a fallback."""
+    heavy_imports()
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    shared = os.environ["LZS_BENCH_DIR"]
+    dev = pick_device(args)
+    nb = args.blocks if args.blocks is not None else 131072
+    cap = lzs.compressed_max(BLOCK)
+    slot_stride = (cap + 15) // 16 * 16
+    x = workload.fill_device(args.workload, nb, BLOCK, first_block=rank * nb, device=dev)
+    slots = torch.empty((nb, slot_stride), dtype=torch.uint8, device=dev)
+    lens = torch.empty(nb, dtype=torch.int32, device=dev)
+
+    def file_barrier(name: str, timeout: float = 600.0) -> None:
+        open(os.path.join(shared, f"{name}.{rank}"), "w").close()
+        t_end = time.time() + timeout
+        while True:
+            have = sum(1 for n in os.listdir(shared) if n.startswith(name + "."))
+            if have >= world:
+                return
+            if time.time() > t_end:
+                raise SystemExit(f"bench.py: rank {rank}: {have} of {world} ranks reached '{name}'")
+            time.sleep(0.0005)
+
+    for _ in range(args.warmup):
+        lzs.compress_blocks(x, None, cap, slots, lens)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    file_barrier("ready2")
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        lzs.compress_blocks(x, None, cap, slots, lens)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    back, back_len = lzs.decompress_blocks(slots, lens, BLOCK)
+    ok = bool((back_len == BLOCK).all()) and torch.equal(back[:, :BLOCK], x)
+    del back
+    # sampled blocks against the CPU oracle (first, middle, last 64 of the shard)
+    import oracle
+    O = oracle.oracle()
+    exact = True
+    for a in sorted({0, max(0, nb // 2 - 32), max(0, nb - 64)}):
+        b = min(nb, a + 64)
+        want, want_len, _ = oracle.run_blocks(O, x[a:b].cpu().numpy(), threads=2)
+        g, gl = slots[a:b].cpu().numpy(), lens[a:b].cpu().numpy()
+        exact = exact and bool((want_len == gl).all()) and all(
+            np.array_equal(g[i, :gl[i]], want[i, :want_len[i]]) for i in range(b - a))
+    mine = {"rank": rank, "elapsed": elapsed, "kernel_ms": kernel_ms, "bytes_out": int(lens.sum().item()), "round_trip": ok, "oracle": exact}
+    tmp = os.path.join(shared, f".res2.{rank}.tmp")
+    json.dump(mine, open(tmp, "w"))
+    os.replace(tmp, os.path.join(shared, f"res2.{rank}"))
+    if rank != 0:
+        return 0
+    t_end = time.time() + 600
+    while sum(1 for n in os.listdir(shared) if n.startswith("res2.")) < world:
+        if time.time() > t_end:
+            raise SystemExit("bench.py: not every rank delivered its fallback result")
+        time.sleep(0.01)
+    res = [json.load(open(os.path.join(shared, f"res2.{r}"))) for r in range(world)]
+    elapsed = max(r["elapsed"] for r in res)
+    total_in = world * nb * BLOCK
     try:
-        ctypes.CDLL(None).fflush(None)
+        reason = open(os.path.join(shared, "reason")).read().strip()
     except OSError:
-        pass
-    print(json.dumps(result), flush=True)
+        reason = "unknown"
+    avg_ms = float(np.mean(kernel_ms))
+    achieved = nb * BLOCK / (avg_ms * 1e-3) / 1e9
+    emit({
+        "metric": METRIC, "value": total_in * args.steps / elapsed / 1e9, "unit": "GB/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"FALLBACK: {world * nb} independent 64 KiB blocks, class '{args.workload}', {nb} per GPU generated on "
+                               f"that GPU, compressed there; NO scatter / gather (the RCCL job did not complete)",
+                   "class": args.workload, "blocks_per_gpu": nb, "block_bytes": BLOCK,
+                   "sharding": "independent shards, no data-path collective, ranks synchronised through files",
+                   "compression_ratio": sum(r["bytes_out"] for r in res) / total_in},
+        "fallback": {"reason": reason, "what": "compute-only weak scaling; value is NOT the end-to-end rate of config 5"},
+        "compute_only_GBps": total_in * args.steps / elapsed / 1e9,
+        "per_rank_elapsed_s": [r["elapsed"] for r in res],
+        "checks": {"every_rank_round_trip_on_device": all(r["round_trip"] for r in res),
+                   "sampled_blocks_equal_oracle": all(r["oracle"] for r in res)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "lzs_compress_blocks_wg_kernel (rank 0's launches)",
+                     "algorithmic_bytes_per_launch": {"read_input": nb * BLOCK}, "avg_kernel_ms": avg_ms},
+    })
+    return 0
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="text", choices=workload.CLASS_NAMES)
-    ap.add_argument("--blocks", type=int, default=None,
-                    help="64 KiB blocks per GPU (default: 16384 = 1 GiB at N = 1, 131072 = 8 GiB at N > 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single-stream", action="store_true", help="skip the secondary single_stream line (profiling runs)")
-    ap.add_argument("--sharded-job", action="store_true",
-                    help="run the N > 1 job (scatter / compress / gather over torch.distributed) even at N = 1: "
-                         "exercises that code path with the nccl backend on a one-GPU box")
-    args = ap.parse_args()
+def config5_world1(args, dev) -> dict:
+    """N = 1 only, after the headline: the config-5 job at world size 1 on the nccl backend (no peers:
+    the scatter and the gather move nothing over xGMI), 8 GiB in chunks -- the same fields the N > 1
+    lines carry, so the scaling curve's first point can be read on the same basis."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=300))
+    try:
+        sub = argparse.Namespace(**vars(args))
+        sub.blocks = 131072 if args.blocks in (None, 16384) else args.blocks
+        sub.steps, sub.warmup = min(args.steps, 3), 1
+        r = run_sharded(sub, dist, 0, 1, dev)
+    finally:
+        dist.destroy_process_group()
+    keep = ("value", "ms_per_step", "steps", "overlap", "chunk_blocks", "chunks_per_rank", "end_to_end_GBps", "phases_ms",
+            "serial_end_to_end_GBps", "compute_only_GBps", "overlapped_step", "gathered_bytes", "checks")
+    out = {k: r[k] for k in keep}
+    out["workload"] = r["config"]["workload"]
+    return out
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif args.sharded_job:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", torch.cuda.current_device())
-    if world > 1 or args.sharded_job:
-        run_sharded(args, dist, rank, world, dev)
-        return
-    if args.blocks is None:
-        args.blocks = 16384
 
-    # ---- this rank's shard: blocks [rank*nb, (rank+1)*nb) of the seeded class, into HBM
-    nb = args.blocks
-    host = workload.fill(args.workload, nb, BLOCK, first_block=rank * nb)
+def single(args) -> int:
+    """N = 1: BASELINE.json configs[1], in this process."""
+    heavy_imports()
+    dev = pick_device(args)
+    if args.sharded_job:
+        os.environ["WORLD_SIZE"], os.environ["RANK"] = "1", "0"
+        return worker_job(args)
+    nb = args.blocks if args.blocks is not None else 16384
+
+    # ---- the blocks of the seeded class, into HBM
+    host = workload.fill(args.workload, nb, BLOCK, first_block=0)
     x = torch.from_numpy(host).to(dev)
     slot_stride = (lzs.compressed_max(BLOCK) + 15) // 16 * 16
     slots = torch.empty((nb, slot_stride), dtype=torch.uint8, device=dev)
@@ -299,91 +676,115 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
-    total_in = world * nb * BLOCK * args.steps
+    total_in = nb * BLOCK * args.steps
     lens_h = lens.cpu().numpy()
     ratio = float(lens_h.sum()) / (nb * BLOCK)
 
-    if rank == 0:
-        avg_ms = float(np.mean(kernel_ms))
-        traffic, traffic_note = pmc_traffic(args.workload) if nb == 16384 else (None, "the counters were taken at 16384 blocks per launch")
-        in_bytes = nb * BLOCK
-        algo_bytes = in_bytes + int(lens_h.sum()) + 4 * nb
-        achieved = in_bytes / (avg_ms * 1e-3) / 1e9
-        result = {
-            "metric": "input GB/s on 64KiB blocks, bit-exact vs C ref",
-            "value": total_in / elapsed / 1e9,
-            "unit": "GB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": f"{nb} independent 64 KiB blocks per GPU ({nb * BLOCK >> 20} MiB), "
-                                   f"class '{args.workload}' (seeded generator), device-resident",
-                       "class": args.workload, "blocks_per_gpu": nb, "block_bytes": BLOCK,
-                       "sharding": f"blocks/{world} per rank, no data-path collective",
-                       "compression_ratio": ratio},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic if traffic else traffic_note,
-                         "kernel": "lzs_compress_blocks_wg_kernel",
-                         "algorithmic_bytes_per_launch": {"read_input": in_bytes,
-                                                          "total_read_plus_written": algo_bytes},
-                         "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
-                         "median_kernel_ms": float(np.median(kernel_ms)),
-                         "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
-        }
-        if world == 1:
-            # the box's own streaming figure next to the 8 TB/s of the data sheet (report
-            # the fraction against both): a device-to-device copy of the same 1 GiB, read + written
-            try:
-                y = torch.empty_like(x)
-                for _ in range(2):
-                    y.copy_(x)
-                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                c0.record()
-                for _ in range(10):
-                    y.copy_(x)
-                c1.record()
-                torch.cuda.synchronize()
-                copy_gbps = 2.0 * x.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-                del y
-                result["roofline"]["measured_device_copy_GBps"] = copy_gbps
-                result["roofline"]["frac_of_measured_copy"] = result["roofline"]["total_GBps"] / copy_gbps
-                result["roofline"]["measured_copy_note"] = ("torch device-to-device copy of the input tensor, bytes read + written per second; "
-                                                             "frac_of_measured_copy = the kernel's read + written bytes per second over it")
-            except Exception as exc:                       # noqa: BLE001
-                result["roofline"]["measured_device_copy_GBps"] = None
-                result["roofline"]["measured_copy_note"] = f"copy measurement failed: {exc}"
-        if world == 1 and not args.no_single_stream:
-            # secondary, outside the timed region: the same bytes as ONE stream through
-            # lzs_compress_stream_device, wall clock around the synchronous call
-            try:
-                flat = x.reshape(-1)
-                buf, nbytes = lzs.compress_stream(flat)
-                t = time.perf_counter()
-                buf, nbytes = lzs.compress_stream(flat, buf)
-                dt = time.perf_counter() - t
-                result["single_stream"] = {"entry": "lzs_compress_stream_device", "input_bytes": int(flat.numel()),
-                                           "compressed_bytes": nbytes, "ms": dt * 1e3,
-                                           "value": flat.numel() / dt / 1e9, "unit": "GB/s"}
-                back, got = lzs.decompress_stream(buf[:nbytes], flat.numel() + 16)
-                t = time.perf_counter()
-                back, got = lzs.decompress_stream(buf[:nbytes], flat.numel() + 16, back)
-                dt = time.perf_counter() - t
-                result["single_stream"]["decompress"] = {
-                    "entry": "lzs_decompress_stream_device", "ms": dt * 1e3, "value": got / dt / 1e9,
-                    "unit": "GB/s of output", "round_trip": bool(got == flat.numel() and torch.equal(back[:got], flat))}
-            except Exception as exc:                      # never let the extra line spoil the contract line
-                result["single_stream"] = {"error": str(exc)}
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(host, lens_h, slots)
+    avg_ms = float(np.mean(kernel_ms))
+    traffic, traffic_note = pmc_traffic(args.workload) if nb == 16384 else (None, "the counters were taken at 16384 blocks per launch")
+    in_bytes = nb * BLOCK
+    algo_bytes = in_bytes + int(lens_h.sum()) + 4 * nb
+    achieved = in_bytes / (avg_ms * 1e-3) / 1e9
+    result = {
+        "metric": METRIC,
+        "value": total_in / elapsed / 1e9,
+        "unit": "GB/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"{nb} independent 64 KiB blocks per GPU ({nb * BLOCK >> 20} MiB), "
+                               f"class '{args.workload}' (seeded generator), device-resident",
+                   "class": args.workload, "blocks_per_gpu": nb, "block_bytes": BLOCK,
+                   "sharding": "one GPU, no data-path collective",
+                   "compression_ratio": ratio},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic if traffic else traffic_note,
+                     "kernel": "lzs_compress_blocks_wg_kernel",
+                     "algorithmic_bytes_per_launch": {"read_input": in_bytes,
+                                                      "total_read_plus_written": algo_bytes},
+                     "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
+                     "median_kernel_ms": float(np.median(kernel_ms)),
+                     "total_GBps": algo_bytes / (avg_ms * 1e-3) / 1e9},
+    }
+    # the box's own streaming figure next to the 8 TB/s of the data sheet (report
+    # the fraction against both): a device-to-device copy of the same 1 GiB, read + written
+    try:
+        y = torch.empty_like(x)
+        for _ in range(2):
+            y.copy_(x)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            y.copy_(x)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2.0 * x.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del y
+        result["roofline"]["measured_device_copy_GBps"] = copy_gbps
+        result["roofline"]["frac_of_measured_copy"] = result["roofline"]["total_GBps"] / copy_gbps
+        result["roofline"]["measured_copy_note"] = ("torch device-to-device copy of the input tensor, bytes read + written per second; "
+                                                     "frac_of_measured_copy = the kernel's read + written bytes per second over it")
+    except Exception as exc:                       # noqa: BLE001
+        result["roofline"]["measured_device_copy_GBps"] = None
+        result["roofline"]["measured_copy_note"] = f"copy measurement failed: {exc}"
+    if not args.no_single_stream:
+        # secondary, outside the timed region: the same bytes as ONE stream through
+        # lzs_compress_stream_device, wall clock around the synchronous call
+        try:
+            flat = x.reshape(-1)
+            buf, nbytes = lzs.compress_stream(flat)
+            t = time.perf_counter()
+            buf, nbytes = lzs.compress_stream(flat, buf)
+            dt = time.perf_counter() - t
+            result["single_stream"] = {"entry": "lzs_compress_stream_device", "input_bytes": int(flat.numel()),
+                                       "compressed_bytes": nbytes, "ms": dt * 1e3,
+                                       "value": flat.numel() / dt / 1e9, "unit": "GB/s"}
+            back, got = lzs.decompress_stream(buf[:nbytes], flat.numel() + 16)
+            t = time.perf_counter()
+            back, got = lzs.decompress_stream(buf[:nbytes], flat.numel() + 16, back)
+            dt = time.perf_counter() - t
+            result["single_stream"]["decompress"] = {
+                "entry": "lzs_decompress_stream_device", "ms": dt * 1e3, "value": got / dt / 1e9,
+                "unit": "GB/s of output", "round_trip": bool(got == flat.numel() and torch.equal(back[:got], flat))}
+            del buf, back
+        except Exception as exc:                      # never let the extra line spoil the contract line
+            result["single_stream"] = {"error": str(exc)}
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(host, lens_h, slots)
+    if not args.no_config5:
+        del slots, x
+        try:
+            result["config5_world1"] = config5_world1(args, dev)
+        except Exception as exc:                      # noqa: BLE001 -- an extra, never the contract line's problem
+            result["config5_world1"] = {"error": f"{type(exc).__name__}: {exc}"}
     emit(result)
+    return 0
+
+
+def main() -> int:
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    role = os.environ.get("LZS_BENCH_ROLE")
+    if role == "job":
+        return worker_job(args)
+    if role == "independent":
+        return worker_independent(args)
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        return supervise(args, argv)
+    if args.gpus > 1:
+        return self_launch(args, argv)
+    return single(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

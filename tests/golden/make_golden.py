@@ -15,6 +15,9 @@ Outputs
   class_digests.json
         for each synthetic workload class: len[] and SHA-256 of the concatenated
         lzs_compress outputs of the first 256 blocks of 64 KiB (seeded generators)
+  class_digests_full.json
+        the same for ALL 16384 blocks of BASELINE.json configs[1..3] (1 GiB per class), in groups
+        of 1024 blocks: SHA-256 of the group's len[] (uint32 LE) and of its concatenated streams
   text_4k.bin / text_4k.lzs       BASELINE.json configs[0]: first 4096 B of text block 0
   text_block0.lzs                 full stream of text block 0 (64 KiB)
 """
@@ -170,6 +173,22 @@ def main():
             open(os.path.join(HERE, "text_4k.bin"), "wb").write(small)
             open(os.path.join(HERE, "text_4k.lzs"), "wb").write(ref.compress(small))
     json.dump(digests, open(os.path.join(HERE, "class_digests.json"), "w"))
+
+    # ---- the full 1 GiB configurations: 16384 blocks per class, 16 groups of 1024
+    full = {"seed": SEED, "block_len": 65536, "nblocks": 16384, "group": 1024, "classes": {}}
+    for cls, name in enumerate(workload.CLASS_NAMES):
+        groups, total = [], 0
+        for lo in range(0, 16384, 1024):
+            blocks = workload.fill(cls, 1024, 65536, first_block=lo, seed=SEED)
+            out, out_len, _ = oracle.run_blocks(ref, blocks, threads=8)
+            h = hashlib.sha256()
+            for b in range(1024):
+                h.update(out[b, :out_len[b]].tobytes())
+            groups.append({"len_sha256": hashlib.sha256(out_len.astype("<u4").tobytes()).hexdigest(),
+                           "sha256": h.hexdigest(), "bytes": int(out_len.sum())})
+            total += int(out_len.sum())
+        full["classes"][name] = {"groups": groups, "bytes": total, "ratio": total / (16384 * 65536)}
+    json.dump(full, open(os.path.join(HERE, "class_digests_full.json"), "w"), indent=0)
     print("golden fixtures written:", sorted(os.listdir(HERE)))
 
 

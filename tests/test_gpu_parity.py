@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden_bytes, length_bits, uncompressible_sequence
+from conftest import golden_bytes, golden_json, length_bits, uncompressible_sequence
 import lzs_compression_amd as lzs
 from lzs_compression_amd import workload
 
@@ -775,27 +775,44 @@ def test_wave_per_stream_decoders_agree_with_the_default(decoder):
 
 # ------------------------------------------------------------ BASELINE.json full-size configs
 @pytest.mark.parametrize("cls", workload.CLASS_NAMES)
-def test_full_size_1gib_roundtrip_and_sampled_oracle(cls):
-    """configs[1..3]: 1 GiB = 16384 x 64 KiB.  Size-independent properties on the whole
-    gigabyte (decode(encode(x)) == x on device, every length within the worst-case bound,
-    every stream ends with the end marker) + bit-exact comparison with the oracle on a
-    seeded sample of blocks."""
+def test_full_size_1gib_every_block_vs_oracle_and_reference_digests(cls):
+    """configs[1..3]: 1 GiB = 16384 x 64 KiB.  EVERY block's length and bytes against the CPU
+    oracle ("every block compared against the CPU restatement"), every group of 1024
+    blocks against the REAL reference's digests (tests/golden/class_digests_full.json, minted here
+    from oracle/_ref), and, where oracle/_ref travelled, every block against the reference itself;
+    plus the size-independent properties on the whole gigabyte (decode(encode(x)) == x on device,
+    every length within the worst-case bound)."""
     nb, bl = 16384, 65536
-    blocks = workload.fill(cls, nb, bl)
+    full = golden_json("class_digests_full.json")
+    assert full["nblocks"] == nb and full["block_len"] == bl
+    g = full["group"]
+    blocks = workload.fill(cls, nb, bl, seed=full["seed"])
     x = torch.from_numpy(blocks).cuda()
     slots, lens = lzs.compress_blocks(x)
     back, back_len = lzs.decompress_blocks(slots, lens, bl)
     torch.cuda.synchronize()
     assert bool((back_len == bl).all())
     assert torch.equal(back[:, :bl], x)
+    del back
     lens_h = lens.cpu().numpy()
     assert lens_h.max() <= lzs.compressed_max(bl) and lens_h.min() >= 2
-    sample = np.random.default_rng(1).choice(nb, 192, replace=False)
-    sub = slots[torch.from_numpy(sample).cuda()].cpu().numpy()
-    want, want_len, _ = oracle.run_blocks(O, blocks[sample], threads=8)
-    assert (want_len == lens_h[sample]).all()
-    for i in range(len(sample)):
-        assert sub[i, :want_len[i]].tobytes() == want[i, :want_len[i]].tobytes()
+    codecs = [O] + ([oracle.ref()] if oracle.have_ref() else [])
+    total = 0
+    for k, want in enumerate(full["classes"][cls]["groups"]):
+        lo, hi = k * g, (k + 1) * g
+        got, got_len = slots[lo:hi].cpu().numpy(), lens_h[lo:hi]
+        assert hashlib.sha256(got_len.astype("<u4").tobytes()).hexdigest() == want["len_sha256"], (cls, k)
+        h = hashlib.sha256()
+        for b in range(g):
+            h.update(got[b, :got_len[b]].tobytes())
+        assert h.hexdigest() == want["sha256"], (cls, k)
+        total += int(got_len.sum())
+        for codec in codecs:
+            cpu, cpu_len, _ = oracle.run_blocks(codec, blocks[lo:hi], threads=16)
+            assert (cpu_len == got_len).all(), (cls, k)
+            mask = np.arange(cpu.shape[1])[None, :] < cpu_len[:, None]
+            assert np.array_equal(np.where(mask, got[:, :cpu.shape[1]], 0), np.where(mask, cpu, 0)), (cls, k)
+    assert total == full["classes"][cls]["bytes"]
 
 
 def test_small_batch_in_device_memory_decompressed_in_segments():

@@ -20,20 +20,56 @@ def _need_gpu():
         pytest.fail("these tests need a GPU (no fallback exists)")
 
 
-def test_bench_sharded_job_world1_nccl():
+def _bench(args, timeout=900, **extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LZS_BENCH_ROLE", "LZS_BENCH_DIR")}
+    env.update(MASTER_ADDR="127.0.0.1", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r
+
+
+@pytest.mark.parametrize("extra", [["--chunk-blocks", "512"], ["--chunk-blocks", "600"], ["--no-overlap"]])
+def test_bench_sharded_job_world1_nccl(extra):
     """bench.py's N > 1 leg as the driver would start it, forced onto one GPU: device generator,
-    scatter (no peers), compress, compact, gather-v, the on-device round trip and the oracle check
-    of sampled gathered blocks."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sharded-job", "--blocks", "2048",
-                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    the pipelined job (four chunks; ragged chunks; un-overlapped) with its all_gathers on RCCL, the
+    un-overlapped pass for the phase times, the on-device round trip and the oracle check of the
+    gathered streams."""
+    line, _ = _bench(["--gpus", "1", "--sharded-job", "--blocks", "2048", "--steps", "2", "--warmup", "1", "--check-every", "1"] + extra,
+                     MASTER_PORT="29533")
     assert line["n_gpus"] == 1 and line["steps"] == 2
-    assert line["checks"] == {"every_rank_round_trip_on_device": True, "gathered_samples_equal_oracle": True}
-    assert set(line["phases_ms"]) >= {"scatter", "compress", "gather"}
+    assert line["checks"]["every_rank_round_trip_on_device"] is True and line["checks"]["gathered_samples_equal_oracle"] is True
+    assert line["checks"]["gathered_blocks_compared_with_oracle"] == 2048
+    assert line["overlap"] == (extra[0] != "--no-overlap") and line["chunks_per_rank"] == {"512": 4, "600": 4}.get(extra[-1], 1)
+    assert set(line["phases_ms"]) >= {"scatter", "compress", "gather", "step"}
     assert line["gathered_bytes"] > 0 and 0.5 < line["config"]["compression_ratio"] < 0.62
-    assert line["value"] > 0 and line["compute_only_GBps"] >= line["end_to_end_GBps"]
+    assert line["value"] > 0 and line["compute_only_GBps"] > 0 and line["serial_end_to_end_GBps"] > 0
+    assert len(line["overlapped_step"]["stage_compute_ms_rank0_last_step"]) == line["chunks_per_rank"]
+    assert "fallback" not in line
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu_falls_back():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py launches its own ranks (child
+    torch.distributed.run), each rank a supervisor with a worker child.  Two ranks on ONE GPU: RCCL
+    refuses a communicator with a duplicate device, so the first attempt fails for real and every rank
+    takes the no-collective fallback -- the path an 8-GPU lease would take if the RCCL job broke."""
+    line, r = _bench(["--gpus", "2", "--allow-shared-gpu", "--blocks", "1024", "--steps", "2", "--warmup", "1"],
+                     LZS_BENCH_JOB_DEADLINE="240")
+    assert line["n_gpus"] == 2 and "fallback" in line and "failed" in line["fallback"]["reason"], r.stderr[-2000:]
+    assert line["checks"] == {"every_rank_round_trip_on_device": True, "sampled_blocks_equal_oracle": True}
+    assert line["value"] > 0 and len(line["per_rank_elapsed_s"]) == 2
+
+
+def test_bench_default_line_checks_every_block_and_carries_the_config5_fields():
+    """The driver's N = 1 command (smaller batch): the contract line, the every-block comparison with
+    the host codec, and the config-5 job at world size 1 with the fields of the N > 1 lines."""
+    line, _ = _bench(["--gpus", "1", "--blocks", "2048", "--steps", "3", "--warmup", "1", "--no-single-stream"])
+    assert line["n_gpus"] == 1 and line["unit"] == "GB/s" and line["roofline"]["bound"] == "hbm"
+    cb = line["cpu_baseline"]
+    assert cb["gpu_output_bit_exact_on_sample"] is True and cb["check"]["blocks_compared"] == cb["check"]["of"] == 2048
+    c5 = line["config5_world1"]
+    assert "error" not in c5, c5
+    assert c5["checks"]["every_rank_round_trip_on_device"] and c5["checks"]["gathered_samples_equal_oracle"]
+    assert c5["overlap"] is False or c5["chunks_per_rank"] >= 1
 
 
 def test_scatter_and_gather_primitives_world1_nccl():

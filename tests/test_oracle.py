@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden_bytes, length_bits, uncompressible_sequence
+from conftest import golden_bytes, golden_json, length_bits, uncompressible_sequence
 from lzs_compression_amd import workload
 
 O = oracle.oracle()
@@ -101,6 +101,24 @@ def test_class_digests(class_digests, cls):
     back, back_len, _ = oracle.run_blocks(O, out, decompress=True, in_len=out_len,
                                           out_cap=blocks.shape[1], threads=8)
     assert (back_len == blocks.shape[1]).all() and (back == blocks).all()
+
+
+@pytest.mark.parametrize("cls", workload.CLASS_NAMES)
+def test_class_digests_of_the_full_configs_first_4096_blocks(cls):
+    """BASELINE.json configs[1..3] are 16384 blocks per class; tests/golden/class_digests_full.json holds
+    the REAL reference's digests of all of them in groups of 1024.  Here (CPU suite, minutes): the
+    restatement on the first four groups = 4096 blocks = 256 MiB per class; the GPU suite checks
+    all sixteen against the kernel."""
+    full = golden_json("class_digests_full.json")
+    g = full["group"]
+    for k, want in enumerate(full["classes"][cls]["groups"][:4]):
+        blocks = workload.fill(cls, g, full["block_len"], first_block=k * g, seed=full["seed"])
+        out, out_len, _ = oracle.run_blocks(O, blocks, threads=8)
+        assert hashlib.sha256(out_len.astype("<u4").tobytes()).hexdigest() == want["len_sha256"], (cls, k)
+        h = hashlib.sha256()
+        for b in range(g):
+            h.update(out[b, :out_len[b]].tobytes())
+        assert h.hexdigest() == want["sha256"] and int(out_len.sum()) == want["bytes"], (cls, k)
 
 
 def _fuzz_inputs(rng, count):

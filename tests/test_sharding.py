@@ -60,7 +60,7 @@ def _worker(rank, world, port, nblocks, block_len, q):
         dist.destroy_process_group()
 
 
-def _job_worker(rank, world, port, nb, block_len, piece, q):
+def _job_worker(rank, world, port, nb, block_len, piece, chunk, q):
     """The config-5 job (lzs_compression_amd/sharded_job.py, what bench.py --gpus N runs) under gloo:
     CPU tensors, the oracle standing in for the compress kernel, numpy for the compaction."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -71,12 +71,14 @@ def _job_worker(rank, world, port, nb, block_len, piece, q):
         O = oracle.oracle()
         stride = (oracle.compressed_max(block_len) + 15) // 16 * 16
         sharding.P2P_PIECE = piece                      # several pieces per shard, like 8 GiB in 1 GiB pieces
+        calls = []
 
         def compress(x, slots, lens):
-            out, out_len, _ = oracle.run_blocks(O, x.numpy(), threads=1)
+            out, out_len, _ = oracle.run_blocks(O, x.contiguous().numpy(), threads=1)
             slots.zero_()
             slots[:, :out.shape[1]] = torch.from_numpy(out)
             lens.copy_(torch.from_numpy(out_len.astype(np.int32)))
+            calls.append(x.shape[0])
 
         def compact(slots, lens, dense, offsets):
             at = 0
@@ -86,40 +88,64 @@ def _job_worker(rank, world, port, nb, block_len, piece, q):
                 offsets[b] = at
                 at += n
             offsets[slots.shape[0]] = at
-            return at
 
-        job = ShardedCompressJob(nb, block_len, stride, torch.device("cpu"), compress, compact, lambda: None)
+        job = ShardedCompressJob(nb, block_len, stride, torch.device("cpu"), compress, compact, lambda: None, chunk_blocks=chunk)
+        assert job.K == -(-nb // min(nb, chunk or nb)) and job.overlap == (job.K > 1)
         pieces = [torch.from_numpy(workload.fill("text", nb, block_len, first_block=r * nb)) for r in range(world)] if rank == 0 else None
+        full = workload.fill("text", nb * world, block_len)
+        want_out, want_len, _ = oracle.run_blocks(O, full, threads=2)
+        want = np.concatenate([want_out[b, :want_len[b]] for b in range(nb * world)])
+
+        def check():
+            mine = pieces[0] if rank == 0 else job.mine
+            assert np.array_equal(mine.numpy(), workload.fill("text", nb, block_len, first_block=rank * nb))
+            assert len(job.counts) == world and job.nbytes == job.counts[rank]
+            assert job.counts == [int(want_len[r * nb:(r + 1) * nb].sum()) for r in range(world)]
+            if rank == 0:
+                assert sum(job.counts) == len(want) and job.out.numel() == len(want)
+                assert np.array_equal(job.out.numpy(), want)
+                assert np.array_equal(job.all_lens.numpy().astype(np.uint32), want_len)
+            else:
+                assert job.out is None and job.all_lens is None
+
         for _ in range(2):                              # twice: buffers are reused from step to step
+            calls.clear()
             times = job.step(pieces)
-        assert set(times) == {"scatter", "compress", "gather", "total"}
-        mine = pieces[0] if rank == 0 else job.mine
-        assert np.array_equal(mine.numpy(), workload.fill("text", nb, block_len, first_block=rank * nb))
-        if rank == 0:
-            full = workload.fill("text", nb * world, block_len)
-            want_out, want_len, _ = oracle.run_blocks(O, full, threads=2)
-            want = np.concatenate([want_out[b, :want_len[b]] for b in range(nb * world)])
-            assert sum(job.counts) == len(want) and job.out.numel() == len(want)
-            assert np.array_equal(job.out.numpy(), want)
-            assert np.array_equal(job.all_lens.numpy().astype(np.uint32), want_len)
-        else:
-            assert job.out is None and job.all_lens is None
+            assert set(times) >= {"total", "comm_busy", "compute_busy"}
+            assert sum(calls) == nb and len(calls) == job.K
+            check()
+            if rank == 0:
+                job.gathered.fill_(0xEE)                # (nothing of the last step may be needed by the next)
+        phases = job.serial_phases(pieces)              # the un-overlapped pass leaves the same results
+        assert set(phases) == {"scatter", "compress", "gather", "total"}
+        check()
+        job.step(pieces)                                # ... and the pipelined one after it
+        check()
         q.put((rank, "ok"))
-    except Exception as e:  # pragma: no cover - surfaced by the parent
+    except Exception:  # pragma: no cover - surfaced by the parent
         import traceback
         q.put((rank, traceback.format_exc()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nb,block_len,piece", [(2, 5, 4096, 1 << 30), (8, 16, 512, 3000)])
-def test_config5_job_scatter_compress_gather_gloo(world, nb, block_len, piece):
-    """world 8 at config-5 proportions (16 tiny blocks per rank in place of 131072 x 64 KiB, shards
-    cut into several point-to-point pieces like 8 GiB into 1 GiB ones)"""
+@pytest.mark.parametrize("world,nb,block_len,piece,chunk", [
+    (2, 5, 4096, 1 << 30, None),          # un-overlapped: one chunk = the whole shard
+    (2, 7, 2048, 1 << 30, 2),             # pipelined, ragged last chunk (2 + 2 + 2 + 1)
+    (2, 6, 2048, 1 << 30, 1),             # a chunk per block: K + 2 = 8 stages
+    (8, 16, 512, 3000, 4),                # config-5 proportions: 8 ranks, 4 chunks per rank, chunks cut into several pieces
+    (8, 16, 512, 3000, None),
+    (3, 4, 1024, 1 << 30, 3),
+    (1, 6, 2048, 1 << 30, 4),             # world 1: nothing moves between ranks
+])
+def test_config5_job_scatter_compress_gather_gloo(world, nb, block_len, piece, chunk):
+    """The pipelined job (scatter(s) and gather(s-2) in one batch per stage beside compress(s-1))
+    and its un-overlapped form, bytes equal to the oracle's concatenation in block order; world 8 at
+    config-5 proportions (16 tiny blocks per rank in place of 131072 x 64 KiB)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_job_worker, args=(r, world, port, nb, block_len, piece, q)) for r in range(world)]
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, nb, block_len, piece, chunk, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(world)]
