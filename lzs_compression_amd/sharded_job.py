@@ -14,7 +14,8 @@ bounded by its slowest phase and not by the sum of the three:
                                     running beside C(s)
 
     comm lane    : C(0) C(1) q0 C(2) q1 C(3) q2 ...        (q_j: all_gather of the byte counts of
-    compute lane :      X(0)    X(1)    X(2)    ...         chunk j, one int64 per rank)
+    compute lanes:      X(0)    X(1)    X(2)    ...         chunk j, one int64 per rank)
+                                                            (two lanes, chunks alternate: X(j+1) starts in X(j)'s tail)
 
 Every rank issues the same collectives in the same order on ONE communicator: there is nothing
 to deadlock.  Dependencies on the device are events (X(j) waits for C(j), q_j for X(j)); the host
@@ -120,7 +121,10 @@ class ShardedCompressJob:
                     f"but only {free / 1e9:.1f} GB are free; use fewer --blocks per GPU")
         # the root compresses its own piece where it was generated: only peers need a landing buffer
         self.mine = None if self.rank == root else torch.empty((self.nb, block_len), **u8)
-        self.slots = torch.empty((self.cb, slot_stride), **u8)                # one chunk: compact(j) has read it before compress(j+1) writes
+        # two sets of slots, two compute lanes: chunk j on lane j % 2, so the first workgroups of
+        # compress(j+1) fill the CUs that the last ones of compress(j) leave idle (a launch of 8192
+        # blocks on 1280 resident workgroups ends with a tail: 61.4 -> 63+ GB/s at world 1)
+        self.slots = [torch.empty((self.cb, slot_stride), **u8) for _ in range(2 if self.K > 1 else 1)]
         self.lens = torch.empty(self.nb, dtype=torch.int32, device=device)
         self.dense = torch.empty(self.K * self.cb * slot_stride, **u8)         # chunk j at j * cb * slot_stride
         self.offsets = torch.zeros((self.K, self.cb + 1), dtype=torch.int64, device=device)
@@ -135,13 +139,14 @@ class ShardedCompressJob:
         self.chunk_counts: List[List[int]] = []
         self.nbytes = 0
         self.out = None                     # root: the gathered streams of the last step (a view of `gathered`)
-        self.comm, self.comp = _Lane(device), _Lane(device)
+        self.comm = _Lane(device)
+        self.comp = [_Lane(device) for _ in self.slots]
         self.last_stage_ms: Dict[str, List[float]] = {}
 
     @staticmethod
     def memory_needed(nb: int, block_len: int, slot_stride: int, world: int, cb: int, is_root: bool) -> int:
         K = (nb + cb - 1) // cb
-        n = cb * slot_stride + K * cb * slot_stride + nb * 4 + K * (cb + 1) * 8
+        n = (2 if K > 1 else 1) * cb * slot_stride + K * cb * slot_stride + nb * 4 + K * (cb + 1) * 8
         return n + (world * nb * slot_stride + world * nb * 4 if is_root else nb * block_len)
 
     # ------------------------------------------------------------------ pieces of a step
@@ -211,8 +216,9 @@ class ShardedCompressJob:
 
     def _compute_chunk(self, j: int, x_all: torch.Tensor) -> None:
         lo, hi = self._chunk(j)
-        self.compress(x_all[lo:hi], self.slots[:hi - lo], self.lens[lo:hi])
-        self.compact(self.slots[:hi - lo], self.lens[lo:hi], self._dense_chunk(j), self.offsets[j, :hi - lo + 1])
+        slots = self.slots[j % len(self.slots)][:hi - lo]
+        self.compress(x_all[lo:hi], slots, self.lens[lo:hi])
+        self.compact(slots, self.lens[lo:hi], self._dense_chunk(j), self.offsets[j, :hi - lo + 1])
 
     def _finish(self) -> None:
         self.counts = [sum(c[r] for c in self.chunk_counts) for r in range(self.world)]
@@ -247,7 +253,8 @@ class ShardedCompressJob:
         ev_c, ev_c0, ev_x, ev_x0, qwork = [None] * (K + 2), [None] * (K + 2), [None] * K, [None] * K, [None] * K
         t0 = time.perf_counter()
         self.comm.after_current()
-        self.comp.after_current()
+        for lane in self.comp:
+            lane.after_current()
         for s in range(K + 2):
             j = s - 2
             if 0 <= j < K:                       # the byte counts of chunk j: the one place the host waits
@@ -261,12 +268,13 @@ class ShardedCompressJob:
                 if 1 <= s <= K:                  # q_{s-1}, queued behind C(s): it needs X(s-1), which runs beside C(s)
                     self.comm.after(ev_x[s - 1])
                     qwork[s - 1] = dist.all_gather_into_tensor(self.q[s - 1], self._count_of(s - 1), group=self.group, async_op=True)
-            if s < K:                            # X(s): waits for C(s), runs beside C(s+1)
-                with self.comp:
-                    self.comp.after(ev_c[s])
-                    ev_x0[s] = self.comp.mark()
+            if s < K:                            # X(s): waits for C(s), runs beside C(s+1) (and the tail of X(s-1))
+                lane = self.comp[s % len(self.comp)]
+                with lane:
+                    lane.after(ev_c[s])
+                    ev_x0[s] = lane.mark()
                     self._compute_chunk(s, x_all)
-                    ev_x[s] = self.comp.mark()
+                    ev_x[s] = lane.mark()
         with self.comm:
             self._finish()
         self.sync()

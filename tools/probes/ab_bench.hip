@@ -26,6 +26,15 @@ int main(int argc, char **argv)
     std::vector<uint32_t> lens(nb);
     hipMemcpy(lens.data(), d_len, nb * 4, hipMemcpyDeviceToHost);
     unsigned long long tot = 0; for (auto v : lens) tot += v;
-    printf("class %u: mean %.3f ms best %.3f ms (%.2f GB/s), compressed bytes %llu\n", cls, sum / 5, best, nb * 65536.0 / (sum / 5) / 1e6, tot);
+    // identity of the output: FNV-1a over every block's length and bytes (variants must print the same)
+    std::vector<uint8_t> outh((size_t)nb * stride);
+    hipMemcpy(outh.data(), d_out, outh.size(), hipMemcpyDeviceToHost);
+    unsigned long long fnv = 1469598103934665603ull;
+    for (uint32_t b = 0; b < nb; b++) {
+        fnv = (fnv ^ lens[b]) * 1099511628211ull;
+        const uint8_t *q = outh.data() + (size_t)b * stride;
+        for (uint32_t i = 0; i < lens[b]; i++) fnv = (fnv ^ q[i]) * 1099511628211ull;
+    }
+    printf("class %u: mean %.3f ms best %.3f ms (%.2f GB/s), compressed bytes %llu, fnv %016llx\n", cls, sum / 5, best, nb * 65536.0 / (sum / 5) / 1e6, tot, fnv);
     return 0;
 }
