@@ -421,8 +421,61 @@ static size_t one_shot(const char *who, launch_fn launch, uint8_t *out, size_t c
     return got;
 }
 
+/* Buffers beyond what one launch addresses (positions are 32-bit on the device: LZS_BLOCK_MAX of
+ * input, 4 GiB - 1 of output) go through the incremental interface, which carries a stream of any
+ * length across pieces of <= 1 GiB with the history, the undecided tail, a running long match and
+ * the partial output byte kept in a parameter block (lzs_incremental.c): the bytes
+ * are those of the one-shot call, and the reference's size_t lengths (lzs.h:218,229) hold. */
+static size_t long_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n)
+{
+    LzsCompressParameters_t *p = (LzsCompressParameters_t *)malloc(sizeof(*p));
+    if (!p) { fail(LZS_E_NOMEM, "lzs_compress: out of host memory"); return 0; }
+    lzs_compress_init_full(p);
+    p->inPtr = in; p->inLength = n; p->outPtr = out; p->outLength = cap;
+    size_t made = 0;
+    for (;;) {
+        const size_t in_before = p->inLength;
+        const size_t got = lzs_compress_incremental(p, true);
+        made += got;
+        if (p->status & LZS_C_STATUS_ERROR) { made = 0; break; }         /* (reported; lzs_last_error() has the text) */
+        if (p->status & LZS_C_STATUS_END_MARKER) break;
+        if (p->outLength == 0) break;                                     /* the buffer is full: the stream is cut there, like the one-shot call's */
+        if (got == 0 && p->inLength == in_before) {
+            fail(LZS_E_HIP, "lzs_compress: no progress on a long buffer (%zu bytes left)", p->inLength);
+            made = 0;
+            break;
+        }
+    }
+    free(p);
+    return made;
+}
+
+static size_t long_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n)
+{
+    LzsDecompressParameters_t *p = (LzsDecompressParameters_t *)malloc(sizeof(*p));
+    if (!p) { fail(LZS_E_NOMEM, "lzs_decompress: out of host memory"); return 0; }
+    lzs_decompress_init(p);
+    p->inPtr = in; p->inLength = n; p->outPtr = out; p->outLength = cap;
+    size_t made = 0;
+    for (;;) {
+        const size_t in_before = p->inLength;
+        const size_t got = lzs_decompress_incremental(p);
+        made += got;
+        if (p->status & LZS_D_STATUS_ERROR) { made = 0; break; }
+        if (p->status & LZS_D_STATUS_END_MARKER) break;                   /* the one-shot call stops at the first one (:255-260) */
+        if (p->outLength == 0 || p->inLength == 0) break;
+        if (got == 0 && p->inLength == in_before) break;                  /* a token that the input does not finish */
+    }
+    free(p);
+    return made;
+}
+
 size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
+    if (a_inLen > LZS_BLOCK_MAX && a_pOutData && a_pInData) {
+        tls_error[0] = 0;
+        return long_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+    }
     if ((a_inLen > STREAM_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && !getenv("LZS_ONE_WORKGROUP"))
         return stream_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
     return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
@@ -430,6 +483,13 @@ size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *
 
 size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
+    /* a stream longer than one launch takes, or one that may fill more than the 32-bit positions of
+     * the device reach (a length nibble stands for up to 15 bytes: 30 bytes of output per byte) */
+    if (a_pOutData && a_pInData &&
+        (a_inLen > LZS_BLOCK_MAX || (a_outBufferSize > 0xE0000000ull && a_inLen > (0xE0000000ull - 64u) / 30u))) {
+        tls_error[0] = 0;
+        return long_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+    }
     if ((a_inLen > STREAM_DEC_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX &&
         a_pOutData && a_pInData && a_outBufferSize && !getenv("LZS_ONE_WAVE")) {
         const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL, 0, NULL);

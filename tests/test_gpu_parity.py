@@ -568,6 +568,55 @@ def test_largest_stream_the_calls_accept():
         lzs.compress_stream(big)
 
 
+def _bits_before_the_end_marker(stream: np.ndarray, nbits: int) -> np.ndarray:
+    """The last `nbits` bits in front of a stream's end marker (1 1 0000000 + pad: its last set bit
+    is the marker's second bit), as an array of 0/1 -- independent of the byte phase."""
+    tail = np.unpackbits(stream[-(nbits // 8 + 16):])
+    last = int(np.flatnonzero(tail)[-1])
+    return tail[last - 1 - nbits:last - 1]
+
+
+def test_buffers_beyond_the_32_bit_positions_of_a_launch():
+    """The reference's one-shot calls take any size_t (lzs.h:218,229).  5 GiB through the plain
+    lzs_compress() / lzs_decompress() (carried across pieces of <= 1 GiB: history, undecided tail,
+    a long match that runs over a piece border, the partial output byte): the first 16 MiB of the
+    stream are the oracle's, the last 8 Mbit in front of the end marker are those of the oracle run
+    on the tail of the input (the search is a pure function of position and window, greedy parses
+    entered a window earlier have merged), and the round trip is exact."""
+    import ctypes
+    n = 5 << 30
+    part = workload.fill("text", 8192).reshape(-1)                      # 512 MiB of text
+    x = np.empty(n, dtype=np.uint8)
+    for i in range(0, n, part.size):
+        x[i:i + part.size] = part
+    x[(2 << 30) - 1000:(2 << 30) + (40 << 20)] = 9                      # a run across the 2 GiB mark
+    x[(3 << 30) - 7:(3 << 30) + 5] = np.arange(12, dtype=np.uint8)      # something at the old limit
+    cap = lzs.compressed_max(n)
+    out = np.empty(cap, dtype=np.uint8)
+    L = lzs.lib()
+    got = L.lzs_compress(out.ctypes.data, cap, x.ctypes.data, n)
+    assert 0 < got < n, lzs.last_error()
+    head = O.compress(x[:17 << 20].tobytes())
+    assert out[:len(head) - 64].tobytes() == head[:len(head) - 64]
+    tail_in = x[n - (17 << 20):]
+    tail = np.frombuffer(O.compress(tail_in.tobytes()), dtype=np.uint8)
+    nb = 8 << 20
+    assert np.array_equal(_bits_before_the_end_marker(out[:got], nb), _bits_before_the_end_marker(tail, nb))
+    # cut capacity: the prefix of the same stream, and nothing past it is touched
+    small = np.full(1 << 20, 0xA5, dtype=np.uint8)
+    assert L.lzs_compress(small.ctypes.data, (1 << 20) - 7, x.ctypes.data, n) == (1 << 20) - 7
+    assert np.array_equal(small[:(1 << 20) - 7], out[:(1 << 20) - 7]) and (small[(1 << 20) - 7:] == 0xA5).all()
+    del small, tail_in
+    back = np.empty(n + 64, dtype=np.uint8)
+    m = L.lzs_decompress(back.ctypes.data, n + 64, out.ctypes.data, got)
+    assert m == n, lzs.last_error()
+    for i in range(0, n, 1 << 30):
+        assert np.array_equal(back[i:i + (1 << 30)], x[i:i + (1 << 30)]), i
+    # ... and an output buffer that is too small is filled to the brim (lzs-decompression.c:200)
+    assert L.lzs_decompress(back.ctypes.data, (4 << 30) + 11, out.ctypes.data, got) == (4 << 30) + 11
+    assert np.array_equal(back[(4 << 30) - 4096:(4 << 30) + 11], x[(4 << 30) - 4096:(4 << 30) + 11])
+
+
 def test_one_long_stream_decompressed_by_many_wavefronts():
     """lzs_decompress() of a long stream is cut into 8 KiB segments, one wavefront
     each: the segments agree on the decoder state at their borders in a few rounds, decode with
