@@ -164,7 +164,7 @@ size_t lzs_compress_incremental(LzsCompressParameters_t * pParams, bool add_end_
  * stream from a parameter block of 2112 bytes.  Here it is the same device code as above behind
  * the smaller block: there is no room in it to collect small pieces or to park output, so every
  * call that can decide a token reaches the device (~0.1 ms), and a call only takes the input whose
- * worst-case output fits outLength -- give it at least 26 bytes of room, or it returns
+ * worst-case output fits outLength -- give it at least 13 bytes of room, or it returns
  * NO_OUTPUT_BUFFER_SPACE without progress.  lzs_simple_compress() is lzs_compress().
  */
 typedef struct

@@ -165,7 +165,7 @@ static void staging_destroy(void *p)
     for (int i = 0; i < BUF_COUNT; i++)
         if (st->buf[i]) lzs_hip_free(st->buf[i]);
     if (st->stream) lzs_hip_stream_destroy(st->stream);
-    free(st->host_box);
+    if (st->host_box) lzs_hip_host_free(st->host_box);     /* pinned (lzs_incremental.c) */
     if (st->host_tab) lzs_hip_host_free(st->host_tab);
     free(st);
 }

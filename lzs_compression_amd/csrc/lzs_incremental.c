@@ -36,6 +36,7 @@ static void inc_failed_note(const char *who)
 
 void lzs_decompress_init(LzsDecompressParameters_t *p)
 {
+    inc_noted[0] = 0;               /* a new stream: its first failure is reported again */
     if (!p) return;
     p->status = LZS_D_STATUS_NONE;
     memset(p->reserved_, 0, sizeof(p->reserved_));
@@ -56,13 +57,13 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
         p->status = LZS_D_STATUS_INPUT_FINISHED | LZS_D_STATUS_INPUT_STARVED;
         return 0;
     }
+    staging_t *st = NULL;
     if ((p->inLength && !p->inPtr) || (p->outLength && !p->outPtr)) {
         fail(LZS_E_ARG, "%s: NULL buffer", who);
-        p->status = LZS_D_STATUS_ERROR;
-        return 0;
+        goto failed;                /* terminal like every other failure: a loop that never looks at ERROR ends */
     }
     if (require_device() != LZS_OK) goto failed;
-    staging_t *st = staging_get();
+    st = staging_get();
     if (!st) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
 #define HIP_TRY(call, what) do { e = (call); if (e) { hip_fail(e, what); goto failed; } } while (0)
     if (!st->stream) HIP_TRY(lzs_hip_stream_create(&st->stream), "hipStreamCreate");
@@ -138,19 +139,23 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
         if (take <= DEC_SMALL && cap <= DEC_SMALL) {
             /* A small call is all latency: one copy in ([input | state], the input right-aligned
              * before the state), one launch, one copy out ([state | output]), one wait. */
-            if (!st->host_box) st->host_box = (uint8_t *)malloc(INC_BOX_BYTES);
+            /* The box is pinned host memory the device reads and writes in place (hipHostMalloc:
+             * mapped, coherent): no copies are queued at all -- input and state are put there, the
+             * one wavefront works on them over the bus, and the wait for the launch is the only
+             * round trip (two queued copies and their bookkeeping were most of the 0.11 ms). */
+            if (!st->host_box) {
+                void *pinned = NULL;
+                e = lzs_hip_host_malloc(&pinned, INC_BOX_BYTES);
+                if (e) { fail(LZS_E_NOMEM, "%s: pinned host allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
+                st->host_box = (uint8_t *)pinned;
+            }
             uint8_t *box = st->host_box;
-            if (!box) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
-            uint8_t *d_box = NULL;
-            e = staging_reserve(st, BUF_AUX, INC_BOX_BYTES, (void **)&d_box);
-            if (e) { fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto failed; }
             const size_t in_at = DEC_SMALL - ((take + 3u) & ~(size_t)3u);
             memcpy(box + in_at, p->inPtr, take);
+            h.in_used = h.out_made = h.status = 0;
             memcpy(box + DEC_SMALL, &h, sizeof(h));
-            HIP_TRY(lzs_hip_h2d(d_box + in_at, box + in_at, DEC_SMALL - in_at + sizeof(h), stream), "hipMemcpy H2D");
-            HIP_TRY(lzs_hip_launch_decode_resume((lzs_dec_resume_t *)(d_box + DEC_SMALL), d_box + in_at, (uint32_t)take,
-                                                 d_box + DEC_SMALL + DEC_STATE_PAD, (uint32_t)cap, stream), who);
-            HIP_TRY(lzs_hip_d2h(box + DEC_SMALL, d_box + DEC_SMALL, DEC_STATE_PAD + cap, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_launch_decode_resume((lzs_dec_resume_t *)(box + DEC_SMALL), box + in_at, (uint32_t)take,
+                                                 box + DEC_SMALL + DEC_STATE_PAD, (uint32_t)cap, stream), who);
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
             memcpy(&h, box + DEC_SMALL, sizeof(h));
             if (h.in_used > take || h.out_made > cap || h.hist_len > LZS_MAX_HISTORY_SIZE) {
@@ -198,7 +203,8 @@ failed_quiet:                       /* (stream_decompress has reported by itself
     /* Terminal also for a caller that never looks at the ERROR flag (the reference's tools loop
      * until the input is used up and STARVED is reported: utils/lzs-decompress.c:82-121): the
      * input is dropped, so such a loop runs out instead of spinning on the same bytes for ever. */
-    p->inPtr += p->inLength; p->inLength = 0;
+    if (p->inPtr) p->inPtr += p->inLength;
+    p->inLength = 0;
     p->status = LZS_D_STATUS_ERROR | LZS_D_STATUS_INPUT_STARVED | LZS_D_STATUS_INPUT_FINISHED;
     return made;
 }
@@ -213,34 +219,40 @@ failed_quiet:                       /* (stream_decompress has reported by itself
  * (stream_compress_piece).
  *
  * Two blocks share the code below (enc_core_t says where their members are): the reference's
- * LzsCompressParameters_t (14432 bytes: room for 2304 bytes of history, 3600 of input collected
- * before the device is asked, 8 KiB of output that found no room) and its
- * LzsSimpleCompressParameters_t (2112 bytes: the window and the look-ahead, nothing else -- every
- * call goes to the device, and input is only taken as far as its worst-case output fits the
- * caller's buffer). */
+ * LzsCompressParameters_t (14432 bytes: one array that holds 2304 bytes of history and then either
+ * up to 10 KiB of input collected before the device is asked, or up to 11.7 KiB of output that
+ * found no room) and its LzsSimpleCompressParameters_t (2112 bytes: the window, the look-ahead and
+ * nine bytes of output that found no room -- every call that can decide a token goes to the
+ * device, and input is only taken as far as its worst-case output fits the caller's buffer and
+ * those nine bytes). */
 #define INC_HIST      2304u
-#define INC_CARRY_MAX 3600u         /* room for bytes not yet encoded ... */
-#define INC_ACCUM     3072u         /* ... small pieces are collected up to here before the device is asked */
 #define INC_UNDECIDED 15u           /* what a piece leaves undecided at most (LZS_MAX_LOOK_AHEAD_LEN) */
-#define INC_PEND_MAX  8192u
+#define INC_BUF       14368u        /* one array for both: history + bytes not yet encoded, or history + output that found no room */
+#define INC_CARRY_MAX (INC_BUF - INC_HIST)      /* room for bytes not yet encoded ... */
+#define INC_ACCUM     10240u        /* ... small pieces are collected up to here before the device is asked */
+#define INC_PEND_AT   (INC_HIST + INC_UNDECIDED + 1u)   /* after a device call data[] ends below here: the parked output starts here */
+#define INC_PEND_MAX  (INC_BUF - INC_PEND_AT)
 typedef struct __attribute__((packed)) {
     uint32_t data_len;              /* bytes in data[]: history, then carry_len bytes not yet encoded */
     uint32_t carry_len;
-    uint32_t pend_pos, pend_len;    /* output waiting in pend[pend_pos .. pend_len) */
+    uint32_t pend_pos, pend_len;    /* output waiting in data[INC_PEND_AT + pend_pos .. INC_PEND_AT + pend_len): while there is
+                                     * any, no input is collected (data_len < INC_PEND_AT), so the two never meet */
     uint16_t ext_off;               /* != 0: inside a long match at this offset */
     uint8_t  bit_len, bit_val;      /* bits of the partial last output byte, left-aligned */
     uint8_t  marker_waiting;        /* the end marker is among the waiting output */
-    uint8_t  data[INC_HIST + INC_CARRY_MAX];
-    uint8_t  pend[INC_PEND_MAX];
+    uint8_t  data[INC_BUF];
 } enc_priv_t;
 #define ENC_PRIV_AT 40u
 _Static_assert(ENC_PRIV_AT + sizeof(enc_priv_t) <= sizeof(LzsCompressParameters_t), "private state fits");
 
+#define SIMPLE_PEND_MAX 9u
 typedef struct __attribute__((packed)) {
     uint16_t data_len;              /* history (<= 2047), then carry_len bytes not yet encoded (<= 15) */
     uint16_t ext_off;
-    uint8_t  carry_len, bit_len, bit_val;
+    uint8_t  carry_len, bit_len, bit_val;     /* bit_len: bits 0-2; bit 7: the end marker is among the waiting output */
     uint8_t  data[LZS_MAX_HISTORY_SIZE + INC_UNDECIDED];
+    uint8_t  pend_at;               /* output waiting in pend[pend_at & 15 .. pend_at >> 4) */
+    uint8_t  pend[SIMPLE_PEND_MAX];
 } simple_priv_t;
 #define SIMPLE_PRIV_AT 33u
 _Static_assert(sizeof(LzsSimpleCompressParameters_t) == 2112, "size of the reference's LzsSimpleCompressParameters_t");
@@ -256,6 +268,7 @@ typedef struct {
 
 void lzs_compress_init_full(LzsCompressParameters_t *p)
 {
+    inc_noted[0] = 0;               /* a new stream: its first failure is reported again */
     if (!p) return;
     p->status = LZS_C_STATUS_NONE;
     memset(p->reserved_, 0, sizeof(p->reserved_));
@@ -265,6 +278,7 @@ void lzs_compress_init_quick(LzsCompressParameters_t *p) { lzs_compress_init_ful
 
 void lzs_simple_compress_init(LzsSimpleCompressParameters_t *p)
 {
+    inc_noted[0] = 0;
     if (!p) return;
     p->status = LZS_C_STATUS_NONE;
     memset(p->reserved_, 0, sizeof(p->reserved_));
@@ -291,8 +305,7 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
         s->data_len > s->hist_keep + (s->accum > INC_UNDECIDED ? INC_CARRY_MAX : INC_UNDECIDED) || s->carry_len > s->data_len ||
         s->pend_len > s->pend_cap || s->pend_pos > s->pend_len) {
         fail(LZS_E_ARG, "%s: NULL buffer or a parameter block that was not initialised", who);
-        *s->status = LZS_C_STATUS_ERROR;
-        return 0;
+        goto failed;                /* terminal like every other failure: a loop that never looks at ERROR ends */
     }
     /* no device, no stream: say so at the first call, not when the collected input is flushed */
     if (require_device() != LZS_OK) goto failed;
@@ -319,7 +332,8 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
          * waiting undecided included), 8 bytes for the partial byte and the end marker; into the
          * caller's buffer and then into pend[]; one piece is at most 1 GiB. */
         const size_t room = (*s->outLength < ((size_t)1 << 40) ? *s->outLength : ((size_t)1 << 40)) + s->pend_cap;
-        const size_t worst = 8u * room >= 64u ? (8u * room - 64u) / 9u : 0u;       /* input bytes whose output surely fits */
+        /* (at most 9 bits per byte a token covers -- a literal; <= 7 bits carried in, the end marker's 9 and <= 7 of padding) */
+        const size_t worst = 8u * room >= 27u ? (8u * room - 27u) / 9u : 0u;       /* input bytes whose output surely fits */
         if (worst <= s->carry_len) {
             /* (only without pend[]: the caller's buffer alone is too small to promise anything) */
             starved_for_room = 1;
@@ -356,12 +370,8 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
                  who, n, c0, got, (unsigned long long)pc.nbits, pc.c_exit, room);
             goto failed;
         }
-        made += inc_deliver(s, tmp, whole);
-        s->bit_len = last ? 0 : (uint32_t)(pc.nbits & 7u);
-        s->bit_val = s->bit_len ? (uint32_t)(tmp[whole] & (0xFF00u >> s->bit_len)) : 0;
-        s->ext_off = pc.ext_exit;
-        free(tmp); tmp = NULL;
-        /* the new history and carry: bytes [c_exit - hist_keep, n) of prefix + input */
+        /* the new history and carry: bytes [c_exit - hist_keep, n) of prefix + input -- first, because
+         * output that finds no room is parked in the same array, above where this ends */
         {
             const size_t from = pc.c_exit > s->hist_keep ? pc.c_exit - s->hist_keep : 0;
             uint8_t keep[INC_HIST + INC_UNDECIDED + 1u];
@@ -374,6 +384,11 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
             s->data_len = (uint32_t)k;
             s->carry_len = (uint32_t)(n - pc.c_exit);
         }
+        made += inc_deliver(s, tmp, whole);
+        s->bit_len = last ? 0 : (uint32_t)(pc.nbits & 7u);
+        s->bit_val = s->bit_len ? (uint32_t)(tmp[whole] & (0xFF00u >> s->bit_len)) : 0;
+        s->ext_off = pc.ext_exit;
+        free(tmp); tmp = NULL;
         *s->inPtr += take; *s->inLength -= take;
         if (last) {
             if (s->pend_len) s->marker_waiting = 1;
@@ -393,7 +408,8 @@ failed_quiet:
     /* Terminal also for a caller that never looks at the ERROR flag (the reference's tool loops
      * until END_MARKER: utils/lzs-compress.c:91-134): the input is dropped and END_MARKER set
      * next to ERROR, so such a loop ends instead of spinning on the same bytes for ever. */
-    *s->inPtr += *s->inLength; *s->inLength = 0;
+    if (*s->inPtr) *s->inPtr += *s->inLength;
+    *s->inLength = 0;
     *s->status = LZS_C_STATUS_ERROR | LZS_C_STATUS_END_MARKER | LZS_C_STATUS_INPUT_STARVED | LZS_C_STATUS_INPUT_FINISHED;
     return made;
 }
@@ -403,7 +419,7 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
     if (!p) return 0;
     enc_priv_t *pv = (enc_priv_t *)((uint8_t *)p + ENC_PRIV_AT);
     enc_core_t s = { &p->inPtr, &p->outPtr, &p->inLength, &p->outLength, &p->status,
-                     pv->data, INC_HIST, INC_ACCUM, pv->pend, INC_PEND_MAX,
+                     pv->data, INC_HIST, INC_ACCUM, pv->data + INC_PEND_AT, INC_PEND_MAX,
                      pv->data_len, pv->carry_len, pv->pend_pos, pv->pend_len, pv->ext_off, pv->bit_len, pv->bit_val, pv->marker_waiting };
     const size_t made = inc_compress_core(&s, add_end_marker, "lzs_compress_incremental");
     pv->data_len = s.data_len; pv->carry_len = s.carry_len; pv->pend_pos = s.pend_pos; pv->pend_len = s.pend_len;
@@ -416,17 +432,19 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
  * (lzs.h:224-227).  Same calls, same stream; the 2112-byte block has no room to collect input or
  * to park output, so every call with >= 16 bytes to decide is a device call, and a call only takes
  * the input whose worst-case output (9 bits a byte, plus 8 bytes) fits outLength: with less than
- * 26 bytes of room nothing may be promised and the call returns NO_OUTPUT_BUFFER_SPACE at once. */
+ * 13 bytes of room nothing may be promised and the call returns NO_OUTPUT_BUFFER_SPACE at once. */
 size_t lzs_simple_compress_incremental(LzsSimpleCompressParameters_t *p, bool add_end_marker)
 {
     if (!p) return 0;
     simple_priv_t *pv = (simple_priv_t *)((uint8_t *)p + SIMPLE_PRIV_AT);
     enc_core_t s = { &p->inPtr, &p->outPtr, &p->inLength, &p->outLength, &p->status,
-                     pv->data, LZS_MAX_HISTORY_SIZE, INC_UNDECIDED, NULL, 0,
-                     pv->data_len, pv->carry_len, 0, 0, pv->ext_off, pv->bit_len, pv->bit_val, 0 };
+                     pv->data, LZS_MAX_HISTORY_SIZE, INC_UNDECIDED, pv->pend, SIMPLE_PEND_MAX,
+                     pv->data_len, pv->carry_len, pv->pend_at & 15u, pv->pend_at >> 4, pv->ext_off, pv->bit_len & 7u, pv->bit_val,
+                     pv->bit_len >> 7 };
     const size_t made = inc_compress_core(&s, add_end_marker, "lzs_simple_compress_incremental");
     pv->data_len = (uint16_t)s.data_len; pv->carry_len = (uint8_t)s.carry_len;
-    pv->ext_off = (uint16_t)s.ext_off; pv->bit_len = (uint8_t)s.bit_len; pv->bit_val = (uint8_t)s.bit_val;
+    pv->ext_off = (uint16_t)s.ext_off; pv->bit_len = (uint8_t)(s.bit_len | (s.marker_waiting << 7)); pv->bit_val = (uint8_t)s.bit_val;
+    pv->pend_at = (uint8_t)(s.pend_pos | (s.pend_len << 4));
     return made;
 }
 

@@ -175,6 +175,48 @@ def test_incremental_calls_fail_loudly_without_a_gpu():
     assert lzs.IncrementalDecompressor().step(b"", 10) == (b"", 0, lzs.api.STATUS_INPUT_STARVED | lzs.api.STATUS_INPUT_FINISHED)
 
 
+def test_argument_failures_of_the_incremental_calls_are_terminal_too():
+    """A NULL buffer with a non-zero length (no device needed to see that): ERROR, and -- like every
+    other failure -- the input is dropped and END_MARKER / STARVED set, so that the loops of the
+    reference's tools, which never look at ERROR (utils/lzs-compress.c:91-134,
+    utils/lzs-decompress.c:82-121), end instead of calling again with the same arguments."""
+    L = lzs.lib()
+    A = lzs.api
+    c = A.CompressParameters()
+    L.lzs_compress_init_full(ctypes.addressof(c))
+    out = ctypes.create_string_buffer(64)
+    c.inPtr, c.inLength, c.outPtr, c.outLength = None, 10, ctypes.addressof(out), 64
+    assert L.lzs_compress_incremental(ctypes.addressof(c), False) == 0
+    assert c.status & A.STATUS_ERROR and c.status & A.STATUS_END_MARKER and c.inLength == 0
+    assert "NULL buffer" in lzs.last_error()
+    s = A.SimpleCompressParameters()
+    L.lzs_simple_compress_init(ctypes.addressof(s))
+    s.inPtr, s.inLength, s.outPtr, s.outLength = None, 3, ctypes.addressof(out), 64
+    assert L.lzs_simple_compress_incremental(ctypes.addressof(s), True) == 0
+    assert s.status & A.STATUS_ERROR and s.status & A.STATUS_END_MARKER and s.inLength == 0
+    d = A.DecompressParameters()
+    L.lzs_decompress_init(ctypes.addressof(d))
+    src = ctypes.create_string_buffer(b"\x30\xe0\x00", 3)
+    d.inPtr, d.inLength, d.outPtr, d.outLength = ctypes.addressof(src), 3, None, 8
+    assert L.lzs_decompress_incremental(ctypes.addressof(d)) == 0
+    assert d.status == A.STATUS_ERROR | A.STATUS_INPUT_STARVED | A.STATUS_INPUT_FINISHED and d.inLength == 0
+
+
+def test_the_file_tools_exit_non_zero_without_a_gpu(tmp_path):
+    """The bundled tools must not end with exit code 0 and an empty or cut file when the device is
+    missing (silent data loss)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    src = tmp_path / "in.txt"
+    src.write_bytes(b"hello hello hello hello " * 100)
+    bin_dir = os.path.join(ROOT, "lzs_compression_amd", "bin")
+    for tool, arg in (("lzs-compress", str(src)), ("lzs-decompress", os.path.join(ROOT, "tests", "golden", "text_4k.lzs"))):
+        r = subprocess.run([os.path.join(bin_dir, tool), arg, str(tmp_path / "out.bin")], capture_output=True, text=True)
+        assert r.returncode != 0, (tool, r.stdout, r.stderr)
+        assert "no HIP device" in r.stderr or "failed" in r.stderr, r.stderr
+
+
 def test_product_does_not_reference_the_oracle():
     """The shipped package and its native sources never import, link or open oracle/."""
     pkg = os.path.join(ROOT, "lzs_compression_amd")
