@@ -175,7 +175,7 @@ def test_simple_compressor_block_gives_the_same_stream():
     dst = ctypes.create_string_buffer(1024)
     n = lzs.lib().lzs_simple_compress(ctypes.addressof(dst), 1024, plain, len(plain))
     assert dst.raw[:n] == comp
-    for ins, outs in ((len(plain), 1000), (50, 100), (10, 1000), (1000, 26), (1, 64), (512, 512)):
+    for ins, outs in ((len(plain), 1000), (50, 100), (10, 1000), (1000, 26), (1000, 13), (7, 13), (1, 64), (512, 512)):
         assert lzs.incremental_compress(plain, ins, outs, simple=True) == comp, (ins, outs)
     assert lzs.incremental_compress(b"", 10, 100, simple=True) == bytes.fromhex("c000")
     rng = random.Random(3)
@@ -192,7 +192,7 @@ def test_simple_compressor_block_gives_the_same_stream():
                 pos += len(pending)
             if not pending and pos >= len(data):
                 fin = True
-            got, used, status = c.step(pending, rng.randint(26, 4000), fin)
+            got, used, status = c.step(pending, rng.randint(13, 4000), fin)
             out += got
             pending = pending[used:]
             if status & api.STATUS_END_MARKER:
@@ -200,11 +200,11 @@ def test_simple_compressor_block_gives_the_same_stream():
         assert bytes(out) == want, kind
     # too little room to promise anything: no progress, and it says so
     c = lzs.IncrementalCompressor(simple=True)
-    got, used, status = c.step(plain, 20, False)            # takes the 10 bytes whose output would fit, into the look-ahead
-    assert got == b"" and used == 10 and not status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
-    got, used, status = c.step(plain[10:], 20, False)
+    got, used, status = c.step(plain, 5, False)             # takes the 9 bytes whose output would fit (5 + the 9 the block parks), into the look-ahead
+    assert got == b"" and used == 9 and not status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
+    got, used, status = c.step(plain[9:], 5, False)
     assert got == b"" and used == 0 and status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
-    out, pending, fin = bytearray(), plain[10:], False       # with room it goes on from there
+    out, pending, fin = bytearray(), plain[9:], False        # with room it goes on from there
     while not status & api.STATUS_END_MARKER:
         got, used, status = c.step(pending, 100, fin)
         out += got
