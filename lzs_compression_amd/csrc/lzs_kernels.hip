@@ -296,9 +296,18 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
     // streams that expand more than sixfold are runs: there one wavefront per segment wins (60 bytes a step)
     // (n == 0: a batch of blocks with segment tables -- the expansion is not known here)
     if (!old_decode && (n == 0u || (unsigned long long)cap <= 6ull * n)) {
-        hipLaunchKernelGGL(lzs_decode_stream_g8_kernel, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
-                           (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
-                           d_seg_base, d_seg_end, d_out_floor, d_out_limit);
+        // between a quarter and nine tenths of its output a stream is mostly short matches (text: 0.57):
+        // there a second token per trip pays (lzs_decompress_blocks_grp has the numbers)
+        static const int one_token = [] { return getenv("LZS_DEC_ONE_TOKEN") != nullptr; }();
+        const bool two = !one_token && n != 0u && 4ull * n > cap && 10ull * n < 9ull * cap;
+        if (two)
+            hipLaunchKernelGGL(lzs_decode_stream_g8_kernel<true>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
+                               (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
+                               d_seg_base, d_seg_end, d_out_floor, d_out_limit);
+        else
+            hipLaunchKernelGGL(lzs_decode_stream_g8_kernel<false>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
+                               (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
+                               d_seg_base, d_seg_end, d_out_floor, d_out_limit);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
