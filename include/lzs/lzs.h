@@ -59,7 +59,10 @@ extern "C" {
  * Added failure mode: if no usable HIP device exists (or a HIP call fails) the
  * function writes nothing, returns 0 and lzs_last_error() (lzs_batch.h) describes
  * why; a diagnostic is also printed to stderr.  It never falls back to a CPU codec.
- * Inputs are limited to 3 GiB per call.
+ * Any size_t length, like the reference (lzs.h:218): one launch addresses 3 GiB
+ * (LZS_BLOCK_MAX); longer buffers are carried across pieces of <= 1 GiB with the
+ * history, the undecided tail, a long match still running and the partial output
+ * byte kept from piece to piece -- the bytes are those of the one call.
  *
  * Thread-safe: callable concurrently from any number of host threads.
  */
@@ -71,7 +74,8 @@ size_t lzs_compress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_t 
  * ignored), when the output buffer is full (also in the middle of a copy), or when
  * the input runs out in the middle of a token; a match that reaches before the
  * start of the output yields zero bytes.  Returns the number of bytes written.
- * Failure mode and threading as for lzs_compress().
+ * Failure mode and threading as for lzs_compress(); any size_t lengths (streams
+ * beyond LZS_BLOCK_MAX and outputs of 4 GiB and more are decoded in pieces).
  */
 size_t lzs_decompress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_t * a_pInData, size_t a_inLen);
 
@@ -89,8 +93,11 @@ size_t lzs_decompress(uint8_t * a_pOutData, size_t a_outBufferSize, const uint8_
  * A call costs ~0.1 ms whatever its size: feed large pieces (MiB) for throughput
  * (pieces of 16 KiB and more are spread over many wavefronts in both directions);
  * 512-byte pieces, the reference tools' habit, work: the compressor collects them in the block
- * up to 3 KiB before it asks the device (17 MB/s), the decompressor runs at ~4 MB/s on them.
- * Without a HIP device: status = LZS_x_STATUS_ERROR, nothing consumed.
+ * up to 10 KiB before it asks the device (67 MB/s), the decompressor runs at ~4.5 MB/s on them
+ * (one wavefront walks the tokens of a call: ~0.6 us a token).
+ * Any failure (no HIP device, a HIP error, a NULL buffer): status has LZS_x_STATUS_ERROR, the input
+ * is dropped and END_MARKER (compressor) / INPUT_STARVED (decompressor) is set next to it, so that a
+ * loop that never looks at ERROR ends; lzs_last_error() has the text.
  * ------------------------------------------------------------------------- */
 #define LZS_COMPRESS_HISTORY_SIZE   (LZS_MAX_HISTORY_SIZE + LZS_MAX_LOOK_AHEAD_LEN)
 #define LZS_DECOMPRESS_HISTORY_SIZE LZS_MAX_HISTORY_SIZE

@@ -29,7 +29,8 @@ extern "C" {
 #define LZS_E_ARG        (-3)   /* invalid argument                                    */
 #define LZS_E_NOMEM      (-4)   /* device or host allocation failed                    */
 
-/* Largest single block (bytes) a kernel accepts. */
+/* Largest single block (bytes) one launch addresses: the limit of the batch and device-pointer calls
+ * below.  The plain lzs_compress() / lzs_decompress() take any size_t (longer buffers go in pieces). */
 #define LZS_BLOCK_MAX    (3u << 30)
 
 /* Message for the calling thread's most recent failure ("" if none). Never NULL. */
