@@ -54,7 +54,10 @@ int lzs_backend_info(char *buf, size_t cap);
  * d_in_len may be NULL.  `hip_stream` is a hipStream_t passed as void* (NULL = the
  * default stream).  Fastest when d_in, in_stride are multiples of 16 and d_out,
  * out_stride multiples of 4; any alignment is accepted.  No allocation, no
- * synchronisation: safe to capture into a hipGraph.
+ * synchronisation: safe to capture into a hipGraph.  (Once per device and process the
+ * library asks the device how it orders same-address LDS exchanges -- a 0.1 ms kernel on a
+ * stream of its own, at the first entry into the library on that device; `hip_stream` is not
+ * touched by it.  Call lzs_backend_info() first if the very first call is to be captured.)
  */
 int lzs_compress_batch_device(void *d_out, size_t out_stride, size_t out_cap, uint32_t *d_out_len,
                               const void *d_in, size_t in_stride, const uint32_t *d_in_len,

@@ -34,6 +34,11 @@ LZS_HIDDEN int require_device(void)
     if (e != 0 || n <= 0)
         return fail(LZS_E_NO_DEVICE, "no HIP device available (%s); liblzs has no CPU codec",
                     e ? lzs_hip_strerror(e) : "device count is 0");
+    /* the device is asked how it orders same-address LDS exchanges HERE, on a stream of its own,
+     * once per device and process: the first asynchronous launch then finds the answer and neither
+     * allocates nor waits */
+    int mode = 0;
+    if ((e = lzs_hip_chain_mode(NULL, &mode)) != 0) return hip_fail(e, "LDS ordering check");
     return LZS_OK;
 }
 

@@ -116,17 +116,25 @@ int lzs_hip_chain_mode(void *stream, int *mode)
         if (force && force[0] && force[0] != '0') {
             m = 2;
         } else {
+            // On a stream of its own: the caller's stream is neither waited for nor
+            // made to wait, whichever call is the first to ask -- normally require_device(), i.e.
+            // the first entry into the library on this device, not the first "asynchronous" launch.
+            (void)stream;
+            hipStream_t own = nullptr;
             uint32_t *d_bad = nullptr, bad = 0;
-            e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+            e = hipStreamCreateWithFlags(&own, hipStreamNonBlocking);
             if (e != hipSuccess) return (int)e;
-            e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), (hipStream_t)stream);
+            e = hipMalloc((void **)&d_bad, sizeof(uint32_t));
+            if (e != hipSuccess) { (void)hipStreamDestroy(own); return (int)e; }
+            e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), own);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(lzs_lds_order_check_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, d_bad, 16384u);
+                hipLaunchKernelGGL(lzs_lds_order_check_kernel, dim3(512), dim3(256), 0, own, d_bad, 16384u);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
-            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, own);
+            if (e == hipSuccess) e = hipStreamSynchronize(own);
             (void)hipFree(d_bad);
+            (void)hipStreamDestroy(own);
             if (e != hipSuccess) return (int)e;
             m = bad ? 2 : 1;
             if (bad)
