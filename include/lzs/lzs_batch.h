@@ -89,10 +89,10 @@ int lzs_decompress_batch_device_sync(void *d_out, size_t out_stride, size_t out_
 /*
  * ONE stream from device memory, on the whole device: the result of
  * lzs_compress(d_out, out_cap, d_in, in_len) (reference lzs-compression.c:249-467) for buffers
- * already in HBM.  The stream is cut into segments (4 KiB .. 64 KiB), one workgroup each; where each
+ * already in HBM.  The stream is cut into segments (0.5 KiB .. 64 KiB), one workgroup each; where each
  * segment's first token starts is agreed in a few rounds and the segments' bits are shifted to
  * their global offsets, so the bytes are those of the one-shot call.
- * The 4-argument lzs_compress() takes the same route for inputs of 24 KiB and more.
+ * The 4-argument lzs_compress() takes the same route for inputs of 6 KiB and more.
  *
  * d_out must be 4-byte aligned and hold LZS_COMPRESSED_MAX(in_len) + 1024 bytes; ALL of that is
  * overwritten (cleared first).  The result is cut at out_cap as lzs_compress() does.  The call

@@ -27,18 +27,27 @@ LZS_HIDDEN double now_ms(void)
 }
 
 #define STREAM_SEG_MAX 65536u
-#define STREAM_SEG_MIN 4096u
 
-/* Segment size for a stream of n bytes: 64 KiB for long streams, smaller for shorter ones so that
- * they too spread over the device -- a workgroup takes ~1.2 ms per 64 KiB, and every segment pays
- * for a 2.2 KB warm-up of its chains.  Measured (text, host buffers, ms): 64 KiB 1.12 with one
- * workgroup, 0.29 in 4 KiB segments; 1 MiB 1.38 in 64 KiB segments, 0.45 in 4 KiB ones; 4 MiB
- * 2.84 / 1.05 (8 KiB); 16 MiB 5.17 / 4.13 (16 KiB). */
+
+/* Segment size for a stream of n bytes: 64 KiB for long streams, much smaller for shorter ones so
+ * that they too spread over the device -- a workgroup alone on a CU takes 15 us per KiB, and every
+ * segment pays for a 2.2 KB warm-up of its chains (HASH and CHAIN only).  Measured in round 3 (text,
+ * host buffers, ms; tests/dev/seg_small_sweep.py, seg_mid_sweep.py):
+ *            one workgroup   512 B   1 KiB   2 KiB   4 KiB   16 KiB   64 KiB
+ *     8 KiB      0.167       0.127   0.141   0.169   0.227
+ *    64 KiB      0.971       0.138   0.151   0.184   0.248
+ *   256 KiB      3.749       0.169   0.178   0.212   0.275
+ *     1 MiB     15.08        0.357   0.340   0.358   0.417   0.777    1.233
+ *     4 MiB                          0.985   0.916   0.925   1.230    2.684
+ *    16 MiB                          4.032   3.854   3.785   3.961    5.132
+ * (round 2 used 4 KiB up to 2 MiB: 64 KiB in 0.29 ms). */
 static uint32_t stream_seg(size_t n)
 {
     const char *v = getenv("LZS_STREAM_SEG");
-    size_t seg = v ? strtoul(v, NULL, 10) : (n / 512u + 4095u) & ~(size_t)4095u;
-    if (seg < (v ? 256u : STREAM_SEG_MIN)) seg = v ? 256u : STREAM_SEG_MIN;
+    size_t seg = v ? strtoul(v, NULL, 10)
+               : n <= ((size_t)256 << 10) ? 512u : n <= ((size_t)1 << 20) ? 1024u : n <= ((size_t)4 << 20) ? 2048u
+               : n <= ((size_t)32 << 20) ? 4096u : (n / 512u + 4095u) & ~(size_t)4095u;
+    if (seg < 256u) seg = 256u;
     if (seg > STREAM_SEG_MAX) seg = STREAM_SEG_MAX;
     return (uint32_t)(seg & ~(size_t)63u);
 }
@@ -53,9 +62,9 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
                                     piece_t *pc)
 {
     const char *who = pc ? "lzs_compress_incremental" : dev ? "lzs_compress_stream_device" : "lzs_compress";
-    /* a short piece of the incremental interface (its block collects ~10 KiB) is all latency: half
-     * a KiB per workgroup (measured at 512-byte calls: 41 MB/s in 4 KiB segments, 62 in 1 KiB, 67 in 512 B) */
-    const uint32_t STREAM_SEG = pc && n <= 32768u && !getenv("LZS_STREAM_SEG") ? 512u : stream_seg(n);
+    /* (a short piece of the incremental interface, whose block collects ~10 KiB, is all latency too:
+     * at 512-byte calls 41 MB/s in 4 KiB segments, 62 in 1 KiB, 67 in 512 B) */
+    const uint32_t STREAM_SEG = stream_seg(n);
     const uint32_t nseg = n ? (uint32_t)((n + STREAM_SEG - 1) / STREAM_SEG) : 1u;
     const size_t worst = LZS_COMPRESSED_MAX(n - (pc ? pc->c0 : 0)) + 8;
     const int end_marker = !pc || pc->last;

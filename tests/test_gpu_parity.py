@@ -419,7 +419,7 @@ def test_multi_megabyte_single_stream():
 
 
 def test_one_long_stream_on_many_workgroups_vs_oracle():
-    """lzs_compress() of a buffer of 24 KiB or more is cut into segments (4-64 KiB), one workgroup
+    """lzs_compress() of a buffer of 6 KiB or more is cut into segments (0.5-64 KiB), one workgroup
     each, stitched at the bit level.  Same bytes as the reference: every class,
     lengths that are not multiples of the segment, runs and repeats spanning many segments, and
     a capacity that cuts the stream."""
