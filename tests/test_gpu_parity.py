@@ -50,6 +50,19 @@ def _gpu_decompress_many(streams, cap):
     return [out[i, :out_len[i]].tobytes() for i in range(len(streams))]
 
 
+def _gpu_decompress_blocks_kernel(streams, cap):
+    """The same through the device-pointer call: always ONE launch of the eight-streams-per-wavefront
+    block decoder (the host-buffer call cuts small batches into segments for the stream decoder)."""
+    import torch
+    arr, lens = _rows(streams)
+    x = torch.from_numpy(arr).cuda()
+    n = torch.from_numpy(lens.astype(np.int32)).cuda()
+    out, out_len = lzs.decompress_blocks(x, n, cap)
+    torch.cuda.synchronize()
+    out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+    return [out[i, :out_len[i]].tobytes() for i in range(len(streams))]
+
+
 # ------------------------------------------------------------ reference KATs, one-shot ABI
 def test_golden_vector_one_shot():
     """c/src/test/test-lzs-decompression.c:34-96 through lzs_compress()/lzs_decompress()."""
@@ -242,6 +255,92 @@ def test_long_matches_across_chunk_and_pool_boundaries():
         assert c == O.compress(d)
 
 
+def test_matches_into_what_an_open_match_ran_over():
+    """After an open match (longer than the in-kernel extension) only the last offset + 12 of the
+    positions it ran over go into the chains: a position whose 12 bytes repeat one period on inside
+    the match is dominated by that nearer position.  Periods of every size class
+    against runs of many lengths, followed by text that matches INTO the run at its start, its
+    middle, just before the dominated zone ends and at its very end, at distances up to the window,
+    with the next long match close behind (run mode: small pools parsed at once), and with several
+    runs in a row; against the oracle."""
+    rng = np.random.default_rng(777)
+    datas = []
+
+    def rnd(n):
+        return bytes(rng.integers(0, 256, int(n), dtype=np.uint8))
+
+    for period in (1, 2, 3, 5, 12, 13, 16, 17, 63, 64, 65, 127, 128, 129, 500, 1000, 2046, 2047):
+        for run in (70, 90, 200, 700, 2100, 4080, 4081, 4200, 9000):
+            unit = rnd(period)
+            body = (unit * (run // period + 2))[:run]
+            lead = rnd(rng.integers(0, 900))
+            pieces = [lead, unit, body]
+            # text that copies from inside the run: phrase of 3..30 bytes taken at several places
+            for where in (0, run // 2, max(0, run - period - 40), max(0, run - period - 13), max(0, run - period - 12),
+                          max(0, run - 30), max(0, run - 12)):
+                n = int(rng.integers(3, 31))
+                pieces += [rnd(rng.integers(1, 20)), body[where:where + n]]
+            pieces.append(rnd(rng.integers(0, 1500)))
+            pieces.append(body[max(0, run - 2000):][:25])            # ... and from far away, near the window's edge
+            # the next long match close behind, at another period
+            other = rnd(int(rng.integers(1, 40)))
+            pieces += [rnd(rng.integers(0, 12)), other * (int(rng.integers(80, 900)) // len(other) + 1), rnd(5)]
+            datas.append(b"".join(pieces))
+    # several runs in a row with nothing or little between them, zero runs among them
+    for _ in range(40):
+        pieces = [rnd(rng.integers(0, 300))]
+        for _ in range(int(rng.integers(2, 9))):
+            period = int(rng.choice([1, 1, 2, 4, 16, 16, 33, 200]))
+            unit = bytes(period) if rng.integers(0, 3) == 0 else rnd(period)
+            pieces += [(unit * 400)[:int(rng.integers(13, 5000))], rnd(rng.integers(0, 4))]
+        datas.append(b"".join(pieces))
+    comps = _gpu_compress_many(datas)
+    for i, (d, c) in enumerate(zip(datas, comps)):
+        assert c == O.compress(d), i
+    # and as ONE stream each through the segment route (half-KiB segments: a run covers many of them)
+    for d in datas[::7]:
+        assert lzs.compress(d) == O.compress(d)
+
+
+def test_sparse_matches_in_high_entropy_data():
+    """High-entropy mode: after a pool of nearly all literals, positions without a
+    seed walk the 2-byte chain alone, with the full nearest-longest rule.  Random bytes with sparse
+    copies of 2..14 bytes from near and far (several candidates of different lengths for the same
+    two first bytes, the longer one farther away; copies of copies; short runs that seed offset 1),
+    so that the pools stay above 8 bits a position while the matches that exist must all be found;
+    then the same data flowing into text and back (the mode switches with a lag of two pools)."""
+    rng = np.random.default_rng(31337)
+    datas = []
+    text = workload.fill("text", 2, 65536).tobytes()
+    for trial in range(60):
+        buf = bytearray(rng.integers(0, 256, int(rng.integers(2100, 5000)), dtype=np.uint8).tobytes())
+        for _ in range(int(rng.integers(30, 200))):
+            buf += rng.integers(0, 256, int(rng.integers(20, 160)), dtype=np.uint8).tobytes()
+            kind = int(rng.integers(0, 5))
+            back = int(rng.integers(1, min(len(buf), 2300)))
+            n = int(rng.integers(2, 15))
+            if kind == 0:                                      # a plain copy
+                buf += buf[len(buf) - back:len(buf) - back + n]
+            elif kind == 1:                                    # two candidates with the same first bytes: near short, far long
+                far = buf[len(buf) - back:len(buf) - back + n]
+                buf += far[:2] + bytes([far[2] ^ 1 if len(far) > 2 else 7]) + rng.integers(0, 256, 9, dtype=np.uint8).tobytes() + far
+            elif kind == 2:                                    # a short run: offset 1 seeds the search
+                buf += bytes([int(rng.integers(0, 256))]) * int(rng.integers(2, 11))
+            elif kind == 3:                                    # a copy of a copy, one byte shorter
+                c = buf[len(buf) - back:len(buf) - back + n]
+                buf += c + rng.integers(0, 256, 3, dtype=np.uint8).tobytes() + c[:-1]
+            else:                                              # a copy from exactly the window's edge and one past it
+                if len(buf) > 2060:
+                    buf += buf[len(buf) - 2047:len(buf) - 2047 + n] + bytes([1]) + buf[len(buf) - 2049:len(buf) - 2049 + n]
+        if trial % 3 == 0:
+            at = int(rng.integers(0, 60000))
+            buf += text[at:at + int(rng.integers(600, 3000))] + rng.integers(0, 256, 1500, dtype=np.uint8).tobytes() + buf[100:160]
+        datas.append(bytes(buf))
+    comps = _gpu_compress_many(datas)
+    for i, (d, c) in enumerate(zip(datas, comps)):
+        assert c == O.compress(d), i
+
+
 def test_fuzz_mixed_segments_up_to_200k_vs_oracle():
     """Longer inputs stitched from segments of different kinds: runs and periodic repeats far
     longer than the window (the kernel finishes those as one open match and skips most of the
@@ -279,6 +378,56 @@ def test_fuzz_mixed_segments_up_to_200k_vs_oracle():
         assert c == O.compress(d)
     backs = _gpu_decompress_many(comps, 200_000)
     assert backs == datas
+
+
+def test_block_decoder_two_tokens_per_trip():
+    """The block decoder takes a second token in a trip when its copy reads nothing the first writes
+    (DESIGN.md 3.3).  Streams of short matches at SMALL offsets (the second token often depends on
+    the first: must wait for the next trip), literal runs of every length in front of matches,
+    matches of 8 that open an extension right behind a short one, sources before out[0] (zero
+    fill) in the second token; whole, and with the output cut at every one of the last 40
+    positions (the room test of the second token); against the oracle's decoder."""
+    rng = np.random.default_rng(9001)
+    datas = []
+    for trial in range(24):
+        buf = bytearray(rng.integers(97, 123, 40, dtype=np.uint8).tobytes())
+        while len(buf) < 20000:
+            kind = int(rng.integers(0, 6))
+            if kind == 0:                                      # copy of the last few bytes: offset <= length of the two tokens together
+                back = int(rng.integers(1, 17)); n = int(rng.integers(2, 9))
+                for _ in range(n): buf.append(buf[-back])
+            elif kind == 1:                                    # literals, 1..9 of them
+                buf += rng.integers(0, 256, int(rng.integers(1, 10)), dtype=np.uint8).tobytes()
+            elif kind == 2:                                    # a copy from far away, 2..7 bytes
+                back = int(rng.integers(20, min(len(buf), 2047))); n = int(rng.integers(2, 8))
+                buf += buf[len(buf) - back:len(buf) - back + n]
+            elif kind == 3:                                    # exactly 8, and 8 + a few (extension right behind)
+                back = int(rng.integers(20, min(len(buf), 2047))); n = int(rng.integers(8, 12))
+                buf += buf[len(buf) - back:len(buf) - back + n]
+            elif kind == 4:                                    # two short copies back to back from far away
+                for _ in range(2):
+                    back = int(rng.integers(30, min(len(buf), 2047))); n = int(rng.integers(2, 5))
+                    buf += buf[len(buf) - back:len(buf) - back + n]
+            else:                                              # a run
+                buf += bytes([int(rng.integers(0, 256))]) * int(rng.integers(2, 40))
+        datas.append(bytes(buf))
+    comps = _gpu_compress_many(datas)
+    for d, c in zip(datas, comps):
+        assert c == O.compress(d) and 0.25 < len(c) / len(d) < 0.9      # the ratio that selects the two-token form
+    big = max(len(d) for d in datas)
+    for route in (_gpu_decompress_blocks_kernel, _gpu_decompress_many):      # the block decoder; the segment decoder
+        for d, back in zip(datas, route(comps, big)):
+            assert back == d
+    # cut capacities: the last 40 positions (all streams in one batch per capacity: one capacity for all)
+    short = min(len(d) for d in datas)
+    for k in range(0, 40):
+        cap = short - k
+        for c, back in zip(comps, _gpu_decompress_blocks_kernel(comps, cap)):
+            assert back == O.decompress(c, cap)
+    # sources before out[0]: streams that begin in the middle of another one's tokens decode to zeros there
+    junk = [c[cut:] for c in comps[:8] for cut in (7, 64, 333)]
+    for j, back in zip(junk, _gpu_decompress_blocks_kernel(junk, 30000)):
+        assert back == O.decompress(j, 30000)
 
 
 def test_fuzz_decoder_on_garbage_vs_oracle():
