@@ -621,9 +621,15 @@ def config5_world1(args, dev) -> dict:
     lines carry, so the scaling curve's first point can be read on the same basis."""
     import datetime
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(free_port())
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=300))
+    # a rendezvous of its own (not env://: under torch.distributed.run the environment points at the
+    # agent's store, and this process is not one of ITS ranks' workers in the N > 1 sense)
+    agent_store = os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # (else c10d would look for the agent's store at OUR port)
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev,
+                                timeout=datetime.timedelta(seconds=120))
+    finally:
+        if agent_store is not None:
+            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = agent_store
     try:
         sub = argparse.Namespace(**vars(args))
         sub.blocks = 131072 if args.blocks in (None, 16384) else args.blocks

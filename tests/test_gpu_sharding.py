@@ -72,6 +72,22 @@ def test_bench_default_line_checks_every_block_and_carries_the_config5_fields():
     assert c5["overlap"] is False or c5["chunks_per_rank"] >= 1
 
 
+def test_bench_under_torch_distributed_run_with_one_rank():
+    """The driver's launch form at N = 1, should it use it: `torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1`.  The config-5 extra makes a rendezvous of its own there (the environment
+    points at the agent's store, which would be waited for until the timeout: it once took the bench
+    from 9 s to 4 minutes)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LZS_BENCH_ROLE", "LZS_BENCH_DIR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "2048", "--steps", "2",
+                        "--warmup", "1", "--no-single-stream", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=150, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and "error" not in line["config5_world1"], line["config5_world1"]
+    assert line["config5_world1"]["checks"]["gathered_samples_equal_oracle"] is True
+
+
 def test_scatter_and_gather_primitives_world1_nccl():
     code = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
