@@ -783,7 +783,8 @@ def main() -> int:
     if role == "independent":
         return worker_independent(args)
     world = int(os.environ.get("WORLD_SIZE", "0") or 0)
-    if world > 1:
+    # (LZS_BENCH_FORCE_SUPERVISE: tests run the supervisor -> worker -> RCCL rendezvous chain with one rank on a one-GPU box)
+    if world > 1 or (world == 1 and os.environ.get("LZS_BENCH_FORCE_SUPERVISE")):
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
         return supervise(args, argv)

@@ -88,6 +88,24 @@ def test_bench_under_torch_distributed_run_with_one_rank():
     assert line["config5_world1"]["checks"]["gathered_samples_equal_oracle"] is True
 
 
+def test_supervisor_worker_rendezvous_chain_with_one_rank():
+    """What every rank of an N > 1 run does, with N = 1: torch.distributed.run starts bench.py, which
+    supervises a WORKER child; the worker joins the process group through the agent's store
+    (env://, as a grandchild of the agent) and runs the pipelined job on RCCL.  No fallback line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LZS_BENCH_ROLE", "LZS_BENCH_DIR")}
+    env["LZS_BENCH_FORCE_SUPERVISE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "2048", "--chunk-blocks", "512",
+                        "--steps", "2", "--warmup", "1", "--check-every", "4"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                        # the supervisor relays ONE line
+    line = json.loads(lines[0])
+    assert "fallback" not in line and line["overlap"] is True and line["chunks_per_rank"] == 4
+    assert line["checks"]["every_rank_round_trip_on_device"] and line["checks"]["gathered_samples_equal_oracle"]
+
+
 def test_scatter_and_gather_primitives_world1_nccl():
     code = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
