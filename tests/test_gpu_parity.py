@@ -1013,6 +1013,71 @@ def test_full_size_1gib_every_block_vs_oracle_and_reference_digests(cls):
     assert total == full["classes"][cls]["bytes"]
 
 
+@pytest.mark.parametrize("cls", workload.CLASS_NAMES)
+def test_other_seeds_4096_blocks_every_block_vs_oracle(cls):
+    """The same three generators under two other seeds and from another block index on: 4096 blocks
+    (256 MiB) each, every block's length and bytes against the oracle, decoded back on the device
+    by the block decoder and, as one batch of 64, by the segment decoder."""
+    for seed, first in ((workload.DEFAULT_SEED + 1, 0), (0xC0FFEE, 777777)):
+        nb, bl = 4096, 65536
+        blocks = workload.fill(cls, nb, bl, first_block=first, seed=seed)
+        x = torch.from_numpy(blocks).cuda()
+        slots, lens = lzs.compress_blocks(x)
+        back, back_len = lzs.decompress_blocks(slots, lens, bl)
+        torch.cuda.synchronize()
+        assert bool((back_len == bl).all()) and torch.equal(back[:, :bl], x)
+        got, got_len = slots.cpu().numpy(), lens.cpu().numpy()
+        cpu, cpu_len, _ = oracle.run_blocks(O, blocks, threads=16)
+        assert (cpu_len == got_len).all(), (cls, seed)
+        mask = np.arange(cpu.shape[1])[None, :] < cpu_len[:, None]
+        assert np.array_equal(np.where(mask, got[:, :cpu.shape[1]], 0), np.where(mask, cpu, 0)), (cls, seed)
+        out, out_len = lzs.decompress_blocks_sync(slots[:64], got_len[:64], bl)
+        assert (out_len == bl).all() and torch.equal(out[:, :bl], x[:64])
+
+
+def test_device_batch_calls_capture_into_a_hip_graph():
+    """lzs_batch.h says the device-pointer calls neither allocate nor synchronise and may be captured
+    into a hipGraph.  Compress + compaction + decompress of 512 blocks captured once on a side stream
+    (torch.cuda.graph), replayed on three different inputs written into the same buffers."""
+    lzs.backend_info()                                     # (the one-time LDS ordering check happens here, not inside the capture)
+    nb, bl = 512, 65536
+    cap = lzs.compressed_max(bl)
+    stride = (cap + 15) // 16 * 16
+    x = torch.empty((nb, bl), dtype=torch.uint8, device="cuda")
+    slots = torch.empty((nb, stride), dtype=torch.uint8, device="cuda")
+    lens = torch.empty(nb, dtype=torch.int32, device="cuda")
+    dense = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+    back = torch.empty((nb, bl), dtype=torch.uint8, device="cuda")
+    back_len = torch.empty(nb, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    x.copy_(torch.from_numpy(workload.fill("text", nb, bl)))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        lzs.compress_blocks(x, None, cap, slots, lens)     # once outside the capture (lazy module loading)
+        lzs.compact(slots, lens, dense=dense, offsets=offsets)
+        lzs.decompress_blocks(slots, lens, bl, back, back_len)
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            lzs.compress_blocks(x, None, cap, slots, lens)
+            lzs.compact(slots, lens, dense=dense, offsets=offsets)
+            lzs.decompress_blocks(slots, lens, bl, back, back_len)
+    for cls, first in (("lowent", 5), ("random", 9), ("text", 4096)):
+        blocks = workload.fill(cls, nb, bl, first_block=first)
+        x.copy_(torch.from_numpy(blocks))
+        slots.fill_(0xEE); back.fill_(0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(back, x) and bool((back_len == bl).all())
+        want, want_len, _ = oracle.run_blocks(O, blocks, threads=8)
+        got_len = lens.cpu().numpy()
+        assert (got_len == want_len).all()
+        offs = offsets.cpu().numpy()
+        cat = np.concatenate([want[b, :want_len[b]] for b in range(nb)])
+        assert int(offs[-1]) == cat.size and np.array_equal(dense[:cat.size].cpu().numpy(), cat)
+
+
 def test_small_batch_in_device_memory_decompressed_in_segments():
     """lzs_decompress_batch_device_sync(): the segment route for batches whose buffers are already
     in HBM (lengths on the host, synchronous).  Same results as the one-launch device call."""
