@@ -308,14 +308,14 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
         // there a second token per trip pays (lzs_decompress_blocks_grp has the numbers)
         static const int one_token = [] { return getenv("LZS_DEC_ONE_TOKEN") != nullptr; }();
         const bool two = !one_token && n != 0u && 4ull * n > cap && 10ull * n < 9ull * cap;
-        if (two)
-            hipLaunchKernelGGL(lzs_decode_stream_g8_kernel<true>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
-                               (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
-                               d_seg_base, d_seg_end, d_out_floor, d_out_limit);
-        else
-            hipLaunchKernelGGL(lzs_decode_stream_g8_kernel<false>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
-                               (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u,
-                               d_seg_base, d_seg_end, d_out_floor, d_out_limit);
+        const bool wide = !one_token && n != 0u && 10ull * n >= 9ull * cap;      // mostly literals: the 96-bit buffer
+#define LZS_LAUNCH_G8(T, W) hipLaunchKernelGGL((lzs_decode_stream_g8_kernel<T, W>), dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream, \
+                               (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u, \
+                               d_seg_base, d_seg_end, d_out_floor, d_out_limit)
+        if (two) LZS_LAUNCH_G8(true, false);
+        else if (wide) LZS_LAUNCH_G8(false, true);
+        else LZS_LAUNCH_G8(false, false);
+#undef LZS_LAUNCH_G8
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(lzs_decode_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
