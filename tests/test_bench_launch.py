@@ -56,3 +56,16 @@ def test_world_size_must_match():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_the_launcher_never_imports_torch_or_the_library():
+    """The parent of a self-launched run (and every supervisor) must stay clean of the GPU so that it
+    may start other programs: with `torch` and the package made unimportable in the launcher process
+    only, `bench.py --gpus 2` still launches, supervises and relays."""
+    code = ("import sys, runpy; sys.modules['torch'] = None; sys.modules['lzs_compression_amd'] = None; sys.modules['numpy'] = None; "
+            "sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']; runpy.run_path(%r, run_name='__main__')" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LZS_BENCH_ROLE", "LZS_BENCH_DIR")}
+    env.update(LZS_BENCH_WORKER_CMD=STUB, LZS_STUB_MODE="ok")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["from"] == "job"
