@@ -10,6 +10,10 @@ role, rank, world = os.environ["LZS_BENCH_ROLE"], int(os.environ["RANK"]), int(o
 mode = os.environ.get("LZS_STUB_MODE", "ok")
 shared = os.environ["LZS_BENCH_DIR"]
 assert os.path.isdir(shared)
+if os.environ.get("LZS_STUB_PIDFILE"):
+    with open(os.environ["LZS_STUB_PIDFILE"] + ".tmp", "w") as f:
+        f.write(str(os.getpid()))
+    os.replace(os.environ["LZS_STUB_PIDFILE"] + ".tmp", os.environ["LZS_STUB_PIDFILE"])
 if role == "job":
     if mode == "fail_rank1" and rank == 1:
         sys.exit(3)

@@ -69,3 +69,71 @@ def test_the_launcher_never_imports_torch_or_the_library():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["from"] == "job"
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)          # (imports nothing heavy at module level)
+    return mod
+
+
+def test_check_ranges_every_block_and_samples():
+    """What the root compares with the CPU oracle per chunk: with --check-every 1 every block of every chunk
+    of every rank (world 8, ragged last chunk), otherwise the first 1/N and the last block, never twice."""
+    b = _bench_module()
+    nb, cb, world = 37, 8, 8
+    chunks = [(lo, min(nb, lo + cb)) for lo in range(0, nb, cb)]
+    for r in range(world):
+        seen = []
+        for lo, hi in chunks:
+            for a, z in b.check_ranges(lo, hi, 1):
+                seen += list(range(r * nb + a, r * nb + z))
+        assert seen == list(range(r * nb, (r + 1) * nb))
+    for every in (2, 3, 16, 1000):
+        for lo, hi in chunks + [(0, 1), (5, 7)]:
+            got = [i for a, z in b.check_ranges(lo, hi, every) for i in range(a, z)]
+            assert len(got) == len(set(got)) and got[0] == lo and got[-1] == hi - 1 and all(lo <= i < hi for i in got)
+            assert len(got) <= max(2, (hi - lo + every - 1) // every + 1)
+
+
+def test_run_token_names_one_launch():
+    b = _bench_module()
+    tok = b.run_token()
+    assert str(os.getppid()) in tok and tok == b.run_token()
+    os.environ["MASTER_PORT"], keep = "29555", os.environ.get("MASTER_PORT")
+    try:
+        assert b.run_token() != tok or keep == "29555"
+    finally:
+        if keep is None:
+            os.environ.pop("MASTER_PORT")
+        else:
+            os.environ["MASTER_PORT"] = keep
+
+
+def test_a_supervisor_takes_its_worker_along_on_sigterm(tmp_path):
+    """torch.distributed.run ends the remaining ranks with SIGTERM when one fails: the supervisor must end
+    its GPU worker (its own child) with it, not leave it on the device."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("LZS_BENCH_ROLE",)}
+    env.update(LZS_BENCH_WORKER_CMD=STUB, LZS_STUB_MODE="hang_rank0", LZS_BENCH_DIR=str(tmp_path), WORLD_SIZE="1", RANK="0",
+               LZS_BENCH_FORCE_SUPERVISE="1", LZS_STUB_PIDFILE=str(tmp_path / "worker.pid"))
+    sup = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, cwd=ROOT,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t_end = time.time() + 60
+    while not (tmp_path / "worker.pid").exists() and time.time() < t_end:
+        time.sleep(0.05)
+    pid = int((tmp_path / "worker.pid").read_text())
+    sup.send_signal(signal.SIGTERM)
+    assert sup.wait(timeout=30) != 0
+    for _ in range(100):                                 # the worker is gone (reaped by the supervisor before it left)
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, signal.SIGKILL)                     # (this exact pid: the stub this test started)
+        pytest.fail("the worker outlived its supervisor")

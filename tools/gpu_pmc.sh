@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() { # name, counters...
   name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-stream --no-config5 --workload $WL > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-stream --no-config5 --no-other-classes --workload $WL > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -7,11 +7,11 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu.txt
 timeout 600 python bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 | tee $OUT/bench_text.json
-timeout 300 python bench.py --steps 10 --warmup 2 --workload lowent --no-config5 2>/dev/null | tail -1 | tee $OUT/bench_lowent.json
-timeout 300 python bench.py --steps 10 --warmup 2 --workload random --no-config5 2>/dev/null | tail -1 | tee $OUT/bench_random.json
+timeout 300 python bench.py --steps 10 --warmup 2 --workload lowent --no-config5 --no-other-classes 2>/dev/null | tail -1 | tee $OUT/bench_lowent.json
+timeout 300 python bench.py --steps 10 --warmup 2 --workload random --no-config5 --no-other-classes 2>/dev/null | tail -1 | tee $OUT/bench_random.json
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config5 > $OUT/rocprof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config5 --no-other-classes > $OUT/rocprof_bench.log 2>&1
 find $OUT/rocprof_stats -name '*stats*.csv' | head -5
 for f in $(find $OUT/rocprof_stats -name '*kernel_stats.csv'); do head -8 $f; done
 # the driver's acceptance hook, LAST: whatever changed during the session, smoke() ran after it

@@ -12,7 +12,7 @@ cd /tmp
 for WL in text lowent random; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/${WL}_$C
-    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${WL}_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-stream --no-config5 --workload $WL > $OUT/${WL}_$C.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${WL}_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-stream --no-config5 --no-other-classes --workload $WL > $OUT/${WL}_$C.log 2>&1
   done
 done
 cd $GRAFT_REPO_ROOT
