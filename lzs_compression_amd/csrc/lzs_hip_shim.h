@@ -37,6 +37,10 @@ int lzs_hip_memset(void *dst, int value, size_t bytes, void *stream);
 int lzs_hip_chain_mode(void *stream, int *mode);
 
 /* Kernel launches (asynchronous on `stream`). */
+/* The LDS ordering check once more beside the first compress launch (under load): 0 not started yet, 1 in flight,
+ * 2 read (a failure switches the device to the order-independent chain build, loudly).  LZS_VERIFY=N in the
+ * environment: every N-th compress launch is re-run in the order-independent form and compared on the device. */
+int lzs_hip_load_check_state(int dev);
 int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                             const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                             uint32_t in_len, uint32_t nblocks, void *stream);

@@ -202,18 +202,48 @@ LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **ou
     return 0;
 }
 
+/* ---- the environment, once per process (lzs_internal.h) */
+static lzs_env_t g_env;
+static int g_env_dev;                                   /* LZS_DEV_ENV: read afresh on every call (tests) */
+static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
+
+static const char *get(const char *name) { return getenv(name); }      /* the host library's one reader of the environment */
+
+static void env_read(lzs_env_t *e)
+{
+    const char *v;
+    memset(e, 0, sizeof *e);
+    v = get("LZS_KEEP_MAX_MB");
+    { const unsigned long mb = v ? strtoul(v, NULL, 10) : 0; e->keep_max = mb ? (size_t)mb << 20 : KEEP_MAX; }
+    e->one_wave = get("LZS_ONE_WAVE") != NULL;
+    e->one_workgroup = get("LZS_ONE_WORKGROUP") != NULL;
+    e->force_stream = get("LZS_FORCE_STREAM") != NULL;
+    v = get("LZS_STREAM_SEG"); e->stream_seg = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
+    v = get("LZS_DEC_SEG");    e->dec_seg = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
+    e->stream_debug = get("LZS_STREAM_DEBUG") != NULL;
+    e->no_marks = get("LZS_NO_MARKS") != NULL;
+    e->no_ones = get("LZS_NO_ONES") != NULL;
+    e->verify_scan = get("LZS_VERIFY_SCAN") != NULL;
+    e->no_tails = get("LZS_NO_TAILS") != NULL;
+    e->no_chunks = get("LZS_NO_CHUNKS") != NULL;
+    e->overlap_off = get("LZS_HOST_SERIAL") != NULL;
+    g_env_dev = get("LZS_DEV_ENV") != NULL;
+}
+
+static void env_once(void) { env_read(&g_env); }
+
+LZS_HIDDEN const lzs_env_t *lzs_env(void)
+{
+    static _Thread_local lzs_env_t fresh;
+    pthread_once(&g_env_once, env_once);
+    if (!g_env_dev) return &g_env;
+    env_read(&fresh);
+    return &fresh;
+}
+
 /* Buffers above the limit are released right after the call (LZS_KEEP_MAX_MB overrides the
  * default of 256 MiB per buffer for programs that compress large buffers over and over). */
-static size_t keep_max(void)
-{
-    static size_t limit = 0;
-    if (!limit) {
-        const char *v = getenv("LZS_KEEP_MAX_MB");
-        const unsigned long mb = v ? strtoul(v, NULL, 10) : 0;
-        limit = mb ? (size_t)mb << 20 : KEEP_MAX;
-    }
-    return limit;
-}
+static size_t keep_max(void) { return lzs_env()->keep_max; }
 
 LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes)
 {
@@ -306,7 +336,7 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
      * (a wavefront takes 9 ms for a 64 KiB block, whatever the batch): then the blocks are cut
      * into segments for many wavefronts, like one long stream. */
     int segmented = 0;
-    if (launch == lzs_hip_launch_decompress && cap32 && !getenv("LZS_ONE_WAVE")) {
+    if (launch == lzs_hip_launch_decompress && cap32 && !lzs_env()->one_wave) {
         size_t total_in = 0;
         for (size_t b = 0; b < nblocks; b++) total_in += in_len_each ? in_len_each[b] : in_len;
         if (nblocks <= BATCH_SEG_MAX_BLOCKS && total_in >= STREAM_DEC_MIN && total_in / nblocks >= 1024u &&
@@ -481,7 +511,7 @@ size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *
         tls_error[0] = 0;
         return long_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
     }
-    if ((a_inLen > STREAM_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && !getenv("LZS_ONE_WORKGROUP"))
+    if ((a_inLen > STREAM_MIN || (a_inLen && lzs_env()->force_stream)) && a_inLen <= LZS_BLOCK_MAX && a_pOutData && a_pInData && !lzs_env()->one_workgroup)
         return stream_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL);
     return one_shot("lzs_compress", lzs_hip_launch_compress, a_pOutData, a_outBufferSize, a_pInData, a_inLen);
 }
@@ -495,8 +525,8 @@ size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t
         tls_error[0] = 0;
         return long_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
     }
-    if ((a_inLen > STREAM_DEC_MIN || (a_inLen && getenv("LZS_FORCE_STREAM"))) && a_inLen <= LZS_BLOCK_MAX &&
-        a_pOutData && a_pInData && a_outBufferSize && !getenv("LZS_ONE_WAVE")) {
+    if ((a_inLen > STREAM_DEC_MIN || (a_inLen && lzs_env()->force_stream)) && a_inLen <= LZS_BLOCK_MAX &&
+        a_pOutData && a_pInData && a_outBufferSize && !lzs_env()->one_wave) {
         const size_t got = stream_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen, 0, NULL, 0, NULL);
         if (got != SIZE_MAX) return got;
     }
@@ -505,8 +535,8 @@ size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t
 
 size_t lzs_decompress_concat(uint8_t *out, size_t out_cap, const uint8_t *in, size_t in_len)
 {
-    if ((in_len > STREAM_DEC_MIN || (in_len && getenv("LZS_FORCE_STREAM"))) && in_len <= LZS_BLOCK_MAX &&
-        out && in && out_cap && !getenv("LZS_ONE_WAVE")) {
+    if ((in_len > STREAM_DEC_MIN || (in_len && lzs_env()->force_stream)) && in_len <= LZS_BLOCK_MAX &&
+        out && in && out_cap && !lzs_env()->one_wave) {
         const size_t got = stream_decompress(out, out_cap, in, in_len, 0, NULL, 1, NULL);
         if (got != SIZE_MAX) return got;
     }

@@ -81,7 +81,7 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
          * whole segments can be decoded; what is left -- the segment with the end marker, the
          * unfinished token at the end of the input, the last bytes before the output is full, a
          * copy still running -- is the one wavefront's below. */
-        if (pv->rem == 0 && p->inLength >= INC_DEC_STREAM_MIN && p->outLength >= 4096u && !getenv("LZS_ONE_WAVE")) {
+        if (pv->rem == 0 && p->inLength >= INC_DEC_STREAM_MIN && p->outLength >= 4096u && !lzs_env()->one_wave) {
             const size_t big = p->inLength < big_limit ? p->inLength : big_limit;
             const uint32_t nb = (pv->qlen + 7u) / 8u;
             uint8_t pre[4] = {0, 0, 0, 0};

@@ -27,6 +27,18 @@ LZS_HIDDEN int fail(int code, const char *fmt, ...);
 LZS_HIDDEN int hip_fail(int hip_error, const char *what);
 LZS_HIDDEN int require_device(void);
 
+/* The development switches of the environment (tools/README.md), read ONCE per process by lzs_env() -- the
+ * entry points ask a struct, not getenv().  LZS_DEV_ENV=1 (set before the first call: the test suites do)
+ * makes every lzs_env() read the environment afresh, so a test can flip a switch between two calls. */
+typedef struct {
+    size_t   keep_max;              /* LZS_KEEP_MAX_MB: staging buffers above it are released after the call */
+    int      one_wave, one_workgroup, force_stream;
+    uint32_t stream_seg, dec_seg;   /* LZS_STREAM_SEG, LZS_DEC_SEG (0: by size) */
+    int      stream_debug, no_marks, no_ones, verify_scan, no_tails, no_chunks;
+    int      overlap_off;           /* LZS_HOST_SERIAL: host-buffer batches copy, run and copy back one after the other */
+} lzs_env_t;
+LZS_HIDDEN const lzs_env_t *lzs_env(void);
+
 /* per-thread staging (lzs_host.c): one HIP stream and grow-only device buffers per host thread */
 enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_MARKS, BUF_COUNT };
 typedef struct {

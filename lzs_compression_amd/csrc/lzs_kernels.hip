@@ -18,7 +18,7 @@
 //                          (DESIGN.md 3.1); the same loop from the middle of a stream for segments
 //                          of one long stream, their bit-level stitch, and the resume of a long
 //                          match for the incremental interface (3.5, 3.7)
-//   compress_variants.inc  "scan" and "chain", the earlier compressors (LZS_KERNEL=, A/B only)
+//   (tools/variants/compress_variants.inc: "scan" and "chain", the earlier compressors -- LZS_KERNEL=, A/B builds only)
 //   decompress_blocks.inc  eight streams per wavefront (3.3); the earlier one-wavefront-per-stream
 //                          decoders for A/B builds
 //   decompress_stream.inc  one stream or a small batch on many wavefronts: scan (a lane per
@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
 
 #include "lzs_hip_shim.h"
@@ -41,7 +42,7 @@ namespace {
 
 #include "kernels/common.inc"
 #ifdef LZS_WITH_VARIANTS   // the earlier compressors ("chain", "scan") and the v1 decoder: A/B builds only
-#include "kernels/compress_variants.inc"
+#include "compress_variants.inc"                 // tools/variants/ (the Makefile adds the path for liblzs_variants.so only)
 #endif
 #include "kernels/compress_wg.inc"
 #include "kernels/decompress_blocks.inc"
@@ -147,6 +148,87 @@ int lzs_hip_chain_mode(void *stream, int *mode)
     return 0;
 }
 
+// ---- the ordering property once more, UNDER LOAD: lzs_hip_chain_mode() asks an idle device.  Beside the
+// first compress launch of a process on a device the same check runs again on a stream of its own -- 262144 patterns
+// this time, so that it overlaps the launch -- and whichever later launch finds it finished reads the verdict: a device
+// that fails it gets the order-independent CHAIN from then on, with a loud note (the launches before may be
+// off in their candidates' order: same format, possibly not the reference's bytes).
+struct LoadCheck { int state; hipStream_t own; hipEvent_t done; uint32_t *d_bad; uint32_t *h_bad; };   // state: 0 not started, 1 in flight, 2 read
+static LoadCheck g_load_check[64];
+static pthread_mutex_t g_load_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void load_check_step(int dev, bool start)
+{
+    if (dev < 0 || dev >= 64 || __atomic_load_n(&g_load_check[dev].state, __ATOMIC_ACQUIRE) == 2) return;
+    pthread_mutex_lock(&g_load_lock);
+    LoadCheck &c = g_load_check[dev];
+    if (c.state == 0 && start) {
+        c.state = 2;                                             // whatever fails below: do not try again
+        if (hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&c.done, hipEventDisableTiming) == hipSuccess &&
+            hipMalloc((void **)&c.d_bad, sizeof(uint32_t)) == hipSuccess &&
+            hipHostMalloc((void **)&c.h_bad, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) {
+            *c.h_bad = 0;
+            (void)hipMemsetAsync(c.d_bad, 0, sizeof(uint32_t), c.own);
+            hipLaunchKernelGGL(lzs_lds_order_check_kernel, dim3(512), dim3(256), 0, c.own, c.d_bad, 262144u);
+            if (hipGetLastError() == hipSuccess &&
+                hipMemcpyAsync(c.h_bad, c.d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c.own) == hipSuccess &&
+                hipEventRecord(c.done, c.own) == hipSuccess)
+                c.state = 1;
+        }
+    } else if (c.state == 1 && hipEventQuery(c.done) == hipSuccess) {
+        if (*c.h_bad) {
+            fprintf(stderr, "liblzs: device %d applied same-address LDS exchanges out of lane order UNDER LOAD (%u lanes off in 262144 "
+                            "patterns beside a compress launch) although it passed the check when idle: switching to the "
+                            "order-independent chain build; the launches so far may differ from the reference's bytes\n", dev, *c.h_bad);
+            __atomic_store_n(&g_chain_mode[dev], 2, __ATOMIC_RELEASE);
+        }
+        (void)hipFree(c.d_bad); (void)hipHostFree(c.h_bad); (void)hipEventDestroy(c.done); (void)hipStreamDestroy(c.own);
+        __atomic_store_n(&c.state, 2, __ATOMIC_RELEASE);
+    }
+    pthread_mutex_unlock(&g_load_lock);
+}
+
+// 0: never asked / finished clean; for tests: has the check beside a launch run to its end, and what did it say
+int lzs_hip_load_check_state(int dev) { return dev >= 0 && dev < 64 ? __atomic_load_n(&g_load_check[dev].state, __ATOMIC_ACQUIRE) : -1; }
+
+// LZS_VERIFY=N: every N-th compress launch of the process is run again with CHAIN in its order-independent form
+// into scratch slots and compared on the device, length and bytes of every block; a difference is an error of the
+// launch (and a line on stderr).  That launch waits for its result: an audit mode, not the asynchronous contract.
+static int verify_every(void)
+{
+    static const int n = [] { const char *v = getenv("LZS_VERIFY"); const long k = v ? strtol(v, nullptr, 10) : 0; return k > 0 ? (int)k : 0; }();
+    return n;
+}
+static unsigned g_launch_count;
+
+static int verify_launch(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
+                         const void *d_in, size_t in_stride, const uint32_t *d_in_len, uint32_t in_len, uint32_t nblocks, hipStream_t stream)
+{
+    const size_t stride = ((size_t)out_cap + 15u) & ~(size_t)15u;
+    uint8_t *d_scratch = nullptr; uint32_t *d_len2 = nullptr, bad = 0;
+    hipError_t e = hipMalloc((void **)&d_scratch, stride * nblocks + 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_len2, sizeof(uint32_t) * ((size_t)nblocks + 1));
+    if (e == hipSuccess) e = hipMemsetAsync(d_len2 + nblocks, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0, stream, d_scratch, stride, out_cap, d_len2,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 1u);
+        hipLaunchKernelGGL(lzs_verify_slots_kernel, dim3(nblocks), dim3(256), 0, stream, (const uint8_t *)d_out, (const uint32_t *)d_out_len,
+                           (const uint8_t *)d_scratch, (const uint32_t *)d_len2, out_stride, stride, nblocks, d_len2 + nblocks);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_len2 + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_scratch); (void)hipFree(d_len2);
+    if (e != hipSuccess) return (int)e;
+    if (bad) {
+        fprintf(stderr, "liblzs: LZS_VERIFY: %u of %u blocks of this launch differ between the ordered-exchange chain build and the "
+                        "order-independent one\n", bad, nblocks);
+        return (int)hipErrorAssert;
+    }
+    return 0;
+}
+
 int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                             const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                             uint32_t in_len, uint32_t nblocks, void *stream)
@@ -177,7 +259,16 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
     hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0,
                        (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
                        (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, (uint32_t)chain_mode);
-    return (int)hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (chain_mode == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) load_check_step(dev, nblocks >= 256u);     // (beside a launch that fills the device)
+        const int every = verify_every();
+        if (every && (__atomic_add_fetch(&g_launch_count, 1u, __ATOMIC_RELAXED) % (unsigned)every) == 0u)
+            return verify_launch(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, (hipStream_t)stream);
+    }
+    return 0;
 }
 
 static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,

@@ -43,8 +43,8 @@ LZS_HIDDEN double now_ms(void)
  * (round 2 used 4 KiB up to 2 MiB: 64 KiB in 0.29 ms). */
 static uint32_t stream_seg(size_t n)
 {
-    const char *v = getenv("LZS_STREAM_SEG");
-    size_t seg = v ? strtoul(v, NULL, 10)
+    const uint32_t v = lzs_env()->stream_seg;
+    size_t seg = v ? v
                : n <= ((size_t)256 << 10) ? 512u : n <= ((size_t)1 << 20) ? 1024u : n <= ((size_t)4 << 20) ? 2048u
                : n <= ((size_t)32 << 20) ? 4096u : (n / 512u + 4095u) & ~(size_t)4095u;
     if (seg < 256u) seg = 256u;
@@ -106,7 +106,7 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
     uint32_t *d_open = d_exit + nseg;
     uint8_t *d_dirty = (uint8_t *)(d_open + 2 * (size_t)nseg);
 
-    const int debug = getenv("LZS_STREAM_DEBUG") != NULL;      /* stage times on stderr */
+    const int debug = lzs_env()->stream_debug;      /* LZS_STREAM_DEBUG: stage times on stderr */
     double t0 = debug ? now_ms() : 0, t1;
     if (!dev) {
         const size_t pre = pc ? pc->prefix_len : 0;
@@ -243,8 +243,8 @@ int lzs_compress_stream_device(void *d_out, size_t out_cap, size_t *out_len, con
  * segments, 10.1 in 8 KiB ones. */
 static uint32_t stream_dec_seg(size_t n)
 {
-    const char *v = getenv("LZS_DEC_SEG");
-    size_t seg = v ? strtoul(v, NULL, 10) : (n / 2048u + 255u) & ~(size_t)255u;
+    const uint32_t v = lzs_env()->dec_seg;
+    size_t seg = v ? v : (n / 2048u + 255u) & ~(size_t)255u;
     if (!v && seg > 4096u) seg = 4096u;
     const size_t most = lzs_hip_dec_segment_bytes();
     if (seg < 256u) seg = 256u;
@@ -300,7 +300,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
     uint8_t *d_dirty = (uint8_t *)(d_counters + 2);
     uint8_t *d_ones = d_dirty + nseg;
 
-    const int debug = getenv("LZS_STREAM_DEBUG") != NULL;
+    const int debug = lzs_env()->stream_debug;
     double t0 = debug ? now_ms() : 0, t1;
     if (!dev) {
         const size_t pre = dp ? dp->prefix_len : 0;
@@ -314,7 +314,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !getenv("LZS_NO_MARKS"), seg, concat, NULL, NULL, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !lzs_env()->no_marks, seg, concat, NULL, NULL, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
@@ -339,7 +339,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
             /* a segment behind the (current) end of the stream keeps what it reported for its last
              * entry: the end may turn out to be a misread of a walk that had not fallen in step */
             if (ended || want == seen[k]) continue;
-            if (((want >> 8) & 1u) && (ones[k] == 2 || (ones[k] && (want & 3u) == 0)) && !getenv("LZS_NO_ONES")) {
+            if (((want >> 8) & 1u) && (ones[k] == 2 || (ones[k] && (want & 3u) == 0)) && !lzs_env()->no_ones) {
                 /* all 0xFF inside a running extension: nothing but nibbles of 15, one every 4 bits
                  * from the cursor on (which is up to 20 bits in if the match token itself straddles
                  * the border) for as long as they start inside the segment -- provided the last of
@@ -362,7 +362,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         }
         if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: round %u scanned %u of %u segments in %.2f ms; %u to redo\n", round, was, nseg, t1 - t0, ndirty); t0 = t1; }
     }
-    if (getenv("LZS_VERIFY_SCAN")) {
+    if (lzs_env()->verify_scan) {
         /* development check: every segment walked in full from its final entry must report what
          * the rounds arrived at (merged walks and the all-0xFF shortcut included) */
         uint32_t *ex2 = (uint32_t *)malloc(sizeof(uint32_t) * nseg), *cn2 = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
@@ -417,10 +417,10 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
          * the chunks alone; (3) one pass over everything.  (3) alone, repeated, does the job too:
          * (1) and (2) are shortcuts, not conditions. */
         const int aligned = ((uintptr_t)d_out & 3u) == 0 && ((uintptr_t)d_origin & 15u) == 0;
-        int tails = left && ndec > 1 && aligned && !getenv("LZS_NO_TAILS");
+        int tails = left && ndec > 1 && aligned && !lzs_env()->no_tails;
         const int had_tails = tails;
         uint32_t stride = 1, round = 1;
-        if (tails && ndec >= 64 && !getenv("LZS_NO_CHUNKS")) {
+        if (tails && ndec >= 64 && !lzs_env()->no_chunks) {
             stride = (ndec + 2047u) / 2048u;                    /* <= 2048 workgroups: all resident at once */
             if (stride < 16u) stride = 16u;
             HIP_TRY(lzs_hip_launch_resolve_chunks(d_out, (uint32_t *)d_origin, before + produce, d_start, ndec, stride, round++, stream), who);
@@ -514,7 +514,7 @@ LZS_HIDDEN int batch_decompress_segments(staging_t *st, void *stream, const char
             }
         }
     }
-    const int debug = getenv("LZS_STREAM_DEBUG") != NULL;
+    const int debug = lzs_env()->stream_debug;
     double t0 = debug ? now_ms() : 0, t1;
     HIP_TRY(lzs_hip_h2d(d_base, base, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
     HIP_TRY(lzs_hip_h2d(d_end, end, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");

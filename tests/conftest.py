@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# liblzs reads its development switches (LZS_FORCE_STREAM, LZS_DEC_SEG, LZS_ONE_WAVE, ...) ONCE per process; tests flip
+# them between calls, which LZS_DEV_ENV -- seen at that first read -- allows (csrc/lzs_internal.h: lzs_env)
+os.environ.setdefault("LZS_DEV_ENV", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")

@@ -55,3 +55,37 @@ def test_order_independent_chain_build_gives_the_same_streams():
     env = dict(os.environ, PYTHONPATH=ROOT, LZS_CHAIN_FALLBACK="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout.split(), r.stderr[-2000:]
+
+
+def test_the_property_is_checked_again_beside_the_first_launch_and_launches_can_be_audited():
+    """the check on an idle device says nothing about a loaded one.  Beside the first compress
+    launch that fills the device the library runs lzs_lds_order_check_kernel once more on a stream of its own
+    (lzs_hip_load_check_state: 1 in flight, 2 read); and with LZS_VERIFY=N every N-th launch is run again with
+    the order-independent chain build and compared on the device, a difference being an error of the launch."""
+    import sys
+    code = (
+        "import ctypes, torch, numpy as np, lzs_compression_amd as lzs\n"
+        "from lzs_compression_amd import workload\n"
+        "L = lzs.lib()\n"
+        "state = L.lzs_hip_load_check_state; state.restype = ctypes.c_int; state.argtypes = [ctypes.c_int]\n"
+        "assert state(0) == 0\n"
+        "x = torch.from_numpy(workload.fill('text', 1024)).cuda()\n"
+        "outs = []\n"
+        "for k in range(6):\n"
+        "    s, n = lzs.compress_blocks(x)\n"
+        "    torch.cuda.synchronize()\n"
+        "    outs.append((s.cpu().numpy(), n.cpu().numpy()))\n"
+        "    assert state(0) in (1, 2), state(0)\n"
+        "assert state(0) == 2, state(0)\n"
+        "assert 'ordered LDS exchange' in lzs.backend_info()\n"
+        "for s, n in outs[1:]:\n"
+        "    assert (n == outs[0][1]).all() and all((s[b, :n[b]] == outs[0][0][b, :n[b]]).all() for b in range(0, 1024, 37))\n"
+        "print('ok')\n")
+    for verify in ("", "2"):
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        env.pop("LZS_VERIFY", None)
+        if verify:
+            env["LZS_VERIFY"] = verify
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout.split(), (verify, r.stderr[-2000:])
+        assert "LZS_VERIFY" not in r.stderr and "out of lane order" not in r.stderr, r.stderr[-2000:]

@@ -45,6 +45,8 @@ def test_bench_sharded_job_world1_nccl(extra):
     assert line["value"] > 0 and line["compute_only_GBps"] > 0 and line["serial_end_to_end_GBps"] > 0
     assert len(line["overlapped_step"]["stage_compute_ms_rank0_last_step"]) == line["chunks_per_rank"]
     assert "fallback" not in line
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1      # (north_star: next to every N's figure)
+    assert line["config"]["memory_plan"] == "as asked"
 
 
 def test_bench_self_launch_two_ranks_on_one_gpu_falls_back():
@@ -56,7 +58,9 @@ def test_bench_self_launch_two_ranks_on_one_gpu_falls_back():
                      LZS_BENCH_JOB_DEADLINE="240")
     assert line["n_gpus"] == 2 and "fallback" in line and "failed" in line["fallback"]["reason"], r.stderr[-2000:]
     assert line["checks"] == {"every_rank_round_trip_on_device": True, "sampled_blocks_equal_oracle": True}
-    assert line["value"] > 0 and len(line["per_rank_elapsed_s"]) == 2
+    # the fallback line carries NO value (a compute-only figure must not be read as config 5's rate)
+    assert line["value"] is None and line["valid"] is False and line["compute_only_GBps"] > 0 and len(line["per_rank_elapsed_s"]) == 2
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] in ("reference", "port")
 
 
 def test_bench_default_line_checks_every_block_and_carries_the_config5_fields():
@@ -70,6 +74,15 @@ def test_bench_default_line_checks_every_block_and_carries_the_config5_fields():
     assert "error" not in c5, c5
     assert c5["checks"]["every_rank_round_trip_on_device"] and c5["checks"]["gathered_samples_equal_oracle"]
     assert c5["overlap"] is False or c5["chunks_per_rank"] >= 1
+    # BASELINE.json configs[2] and [3] on the same line, measured and checked like the headline
+    oc = line["other_classes"]
+    assert set(oc) == {"lowent", "random"}
+    for cls, rec in oc.items():
+        assert "error" not in rec, rec
+        assert rec["value"] > 0 and rec["launches"] == 10 and rec["check"]["bit_exact"] is True and rec["check"]["blocks_compared"] == 2048, (cls, rec)
+        assert rec["roofline"]["frac"] == rec["roofline"]["achieved"] / 8000.0
+    assert oc["lowent"]["compression_ratio"] < 0.06 and 1.10 < oc["random"]["compression_ratio"] < 1.13
+    assert "limiter" in line["roofline"]
 
 
 def test_bench_under_torch_distributed_run_with_one_rank():
