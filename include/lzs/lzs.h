@@ -171,8 +171,10 @@ size_t lzs_compress_incremental(LzsCompressParameters_t * pParams, bool add_end_
  * stream from a parameter block of 2112 bytes.  Here it is the same device code as above behind
  * the smaller block: there is no room in it to collect small pieces or to park output, so every
  * call that can decide a token reaches the device (~0.1 ms), and a call only takes the input whose
- * worst-case output fits outLength -- give it at least 13 bytes of room, or it returns
- * NO_OUTPUT_BUFFER_SPACE without progress.  lzs_simple_compress() is lzs_compress().
+ * worst-case output fits outLength and the nine bytes the block can park.  Like the reference's
+ * (lzs-compression-simple.c:435-647) it makes progress with any outLength >= 1: with little room a
+ * call decides only as many tokens as surely fit (four with one byte of room), status
+ * NO_OUTPUT_BUFFER_SPACE when room was the limit.  lzs_simple_compress() is lzs_compress().
  */
 typedef struct
 {

@@ -334,21 +334,45 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
         const size_t room = (*s->outLength < ((size_t)1 << 40) ? *s->outLength : ((size_t)1 << 40)) + s->pend_cap;
         /* (at most 9 bits per byte a token covers -- a literal; <= 7 bits carried in, the end marker's 9 and <= 7 of padding) */
         const size_t worst = 8u * room >= 27u ? (8u * room - 27u) / 9u : 0u;       /* input bytes whose output surely fits */
-        if (worst <= s->carry_len) {
-            /* (only without pend[]: the caller's buffer alone is too small to promise anything) */
-            starved_for_room = 1;
-            break;
-        }
-        const size_t fits = worst - s->carry_len;
-        size_t take = *s->inLength < fits ? *s->inLength : fits;
-        if (take > ((size_t)1 << 30)) take = (size_t)1 << 30;
-        const int last = add_end_marker && take == *s->inLength;
-        const size_t n = (size_t)s->data_len + take;
+        size_t take;
+        int last;
+        uint32_t stop = 0;
         const uint32_t c0 = s->data_len - s->carry_len;
-        if (!last && n - c0 <= s->accum) {
+        if (worst > s->carry_len) {
+            const size_t fits = worst - s->carry_len;
+            take = *s->inLength < fits ? *s->inLength : fits;
+            if (take > ((size_t)1 << 30)) take = (size_t)1 << 30;
+            last = add_end_marker && take == *s->inLength;
+        } else {
+            /* Little room (the low-memory block parks 9 bytes; lzs-compression-simple.c:435-647 goes on with
+             * outLength >= 1, and so must this -- VERDICT r03): nine bits per BYTE promise nothing here, but
+             * the tokens a piece decides can be counted.  k token starts cover k - 1 bytes before the last of
+             * them begins (<= 9 bits a byte: a literal), and that last one is <= 17 bits and a nibble per 15
+             * bytes of the <= k + 15 there are; 7 bits may be carried in.  So the piece takes just the input
+             * that makes K starts decidable (what stays undecided still fits the block), and when the stream
+             * is to be finished but its marker and padding would not fit as well, the last bytes go out in
+             * pieces that know where the data ends but start no token past `stop`. */
+            size_t K = 0;
+            /* (K + 1 tried: 9 bits for each of the K starts before the last, 17 for that one, and the nibbles of a match
+             * that runs in from the piece before as well as of one that runs out) */
+            while (7u + 9u * K + 17u + 8u * ((K + 1u + INC_UNDECIDED) / 15u + 1u) <= 8u * room) K++;
+            if (K == 0) { starved_for_room = 1; break; }            /* (room < 4 bytes: not with a pend[] of 9) */
+            const size_t want = K + INC_UNDECIDED - s->carry_len;  /* >= K >= 1 */
+            take = *s->inLength < want ? *s->inLength : want;
+            const size_t span = s->carry_len + take;
+            last = add_end_marker && take == *s->inLength;
+            if (last && 7u + 9u * span + 16u > 8u * room) {         /* all of it AND the marker: too much for one call */
+                last = 0;
+                stop = c0 + (uint32_t)(K < span ? K : span);
+                starved_for_room = 1;                               /* (more output is waiting for room: say so) */
+            }
+        }
+        const size_t n = (size_t)s->data_len + take;
+        if (!last && !stop && n - c0 <= s->accum) {
             /* Too little to decide the next token (:641-647) -- or just little: a call costs
              * ~0.12 ms whatever its size, so pieces like the reference tools' 512 bytes are
-             * collected in the block until there are 3 KiB of them (or the stream is finished). */
+             * collected in the block until there are `accum` bytes of them -- up to 10 KiB, what the block's one array
+             * holds beside the history -- or the stream is finished. */
             memcpy(s->data + s->data_len, *s->inPtr, take);
             s->data_len += (uint32_t)take; s->carry_len += (uint32_t)take;
             *s->inPtr += take; *s->inLength -= take;
@@ -357,7 +381,7 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
         piece_t pc;
         memset(&pc, 0, sizeof(pc));
         pc.prefix = s->data; pc.prefix_len = s->data_len;
-        pc.c0 = c0; pc.ext_off = s->ext_off; pc.bit0 = s->bit_len; pc.first = (uint8_t)s->bit_val; pc.last = last;
+        pc.c0 = c0; pc.ext_off = s->ext_off; pc.bit0 = s->bit_len; pc.first = (uint8_t)s->bit_val; pc.last = last; pc.stop = stop;
         const size_t cap = LZS_COMPRESSED_MAX(n - c0) + 16;
         tmp = (uint8_t *)malloc(cap);
         if (!tmp) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
@@ -395,7 +419,7 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
             else *s->status |= LZS_C_STATUS_END_MARKER;
             break;
         }
-        if (s->pend_len || *s->inLength == 0) break;
+        if (s->pend_len || *s->inLength == 0 || stop) break;
     }
     if (s->pend_len || starved_for_room) *s->status |= LZS_C_STATUS_NO_OUTPUT_BUFFER_SPACE;
     if (*s->inLength == 0) *s->status |= LZS_C_STATUS_INPUT_FINISHED | LZS_C_STATUS_INPUT_STARVED;

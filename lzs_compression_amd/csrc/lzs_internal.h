@@ -73,6 +73,8 @@ typedef struct {                    /* a piece of a stream for lzs_compress_incr
     uint32_t c0, ext_off, bit0;
     uint8_t  first;
     int      last;
+    uint32_t stop;          /* != 0: no token starts at or after this position (the data still ends at n: a piece that knows
+                             * where the stream ends but must not produce more than its caller has room for) */
     /* results */
     uint32_t c_exit;        /* everything before it is encoded */
     uint32_t ext_exit;      /* != 0: still inside a long match at this offset */

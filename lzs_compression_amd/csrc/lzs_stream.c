@@ -68,7 +68,8 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
     const uint32_t nseg = n ? (uint32_t)((n + STREAM_SEG - 1) / STREAM_SEG) : 1u;
     const size_t worst = LZS_COMPRESSED_MAX(n - (pc ? pc->c0 : 0)) + 8;
     const int end_marker = !pc || pc->last;
-    const uint32_t lim = end_marker ? (uint32_t)n : (n > LZS_MAX_LOOK_AHEAD_LEN ? (uint32_t)n - LZS_MAX_LOOK_AHEAD_LEN : 0u);
+    uint32_t lim = end_marker ? (uint32_t)n : (n > LZS_MAX_LOOK_AHEAD_LEN ? (uint32_t)n - LZS_MAX_LOOK_AHEAD_LEN : 0u);
+    if (pc && !pc->last && pc->stop) lim = pc->stop < n ? pc->stop : (uint32_t)n;       /* (the caller vouches that the data ends at n) */
     size_t result = 0;
     int e = 0, rc = LZS_OK;
     void *d_in = NULL, *d_out = NULL, *d_aux = NULL, *d_slots = NULL;
@@ -125,7 +126,8 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
         if (pc->ext_off) {
             /* the piece begins inside a long match: its length nibbles first (d_exit as scratch) */
             uint32_t res[4];
-            HIP_TRY(lzs_hip_launch_extend_resume(d_out, pc->bit0, d_in, (uint32_t)n, pc->c0, pc->ext_off, pc->last, d_exit, stream), who);
+            /* (pc->stop: the data is known to end at n -- the run is closed like in a last piece, only the marker waits) */
+            HIP_TRY(lzs_hip_launch_extend_resume(d_out, pc->bit0, d_in, (uint32_t)n, pc->c0, pc->ext_off, pc->last || pc->stop, d_exit, stream), who);
             HIP_TRY(lzs_hip_d2h(res, d_exit, sizeof(res), stream), "hipMemcpy D2H");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
             c_first = res[0];
@@ -163,7 +165,7 @@ LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t 
     if (pc) {
         pc->c_exit = ext_now ? c_first : exitp[nseg - 1];
         pc->ext_exit = ext_now;
-        if (!pc->last && !ext_now && pc->c_exit >= n && n > c_first) {
+        if (!pc->last && !pc->stop && !ext_now && pc->c_exit >= n && n > c_first) {
             /* The last token is a match that reaches the end of the data so far: it may go on in
              * the next piece.  Its full groups of 15 stand; the closing nibble is taken back and
              * the bytes it covered wait for more data (state COMPRESS_EXTENDED, :750-758). */

@@ -198,18 +198,41 @@ def test_simple_compressor_block_gives_the_same_stream():
             if status & api.STATUS_END_MARKER:
                 break
         assert bytes(out) == want, kind
-    # too little room to promise anything: no progress, and it says so
+    # Any room at all makes progress (lzs-compression-simple.c:435-647 goes on with outLength >= 1; VERDICT r03:
+    # below 13 bytes of room this block used to return NO_OUTPUT_BUFFER_SPACE without taking anything, and a
+    # caller with a small buffer span): the reference's pattern with 1, 2 and 5 bytes of room per call ...
+    for ins, outs in ((50, 1), (507, 1), (3, 2), (50, 5), (1, 1), (16, 3)):
+        assert lzs.incremental_compress(plain, ins, outs, simple=True) == comp, (ins, outs)
+    # ... on long matches that are still open when the room runs out, on literals, on text; and in random small pieces
+    for kind in ("text", "lowent", "random", "zeros"):
+        data = _sample(kind, 6000)
+        want = O.compress(data)
+        for ins, outs in ((6000, 1), (100, 2), (17, 5)):
+            assert lzs.incremental_compress(data, ins, outs, simple=True) == want, (kind, ins, outs)
+        c, out, pos, pending, fin, status = lzs.IncrementalCompressor(simple=True), bytearray(), 0, b"", False, 0
+        for _ in range(200000):
+            if not pending and not fin and pos < len(data):
+                pending = data[pos:pos + rng.randint(1, 300)]
+                pos += len(pending)
+            if not pending and pos >= len(data):
+                fin = True
+            got, used, status = c.step(pending, rng.randint(1, 12), fin)
+            assert len(got) <= 12
+            out += got
+            pending = pending[used:]
+            if status & api.STATUS_END_MARKER:
+                break
+        assert bytes(out) == want, kind
+    # every call with room either takes input or hands out bytes (no spinning), and says when room was the limit
     c = lzs.IncrementalCompressor(simple=True)
-    got, used, status = c.step(plain, 5, False)             # takes the 9 bytes whose output would fit (5 + the 9 the block parks), into the look-ahead
-    assert got == b"" and used == 9 and not status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
-    got, used, status = c.step(plain[9:], 5, False)
-    assert got == b"" and used == 0 and status & api.STATUS_NO_OUTPUT_BUFFER_SPACE
-    out, pending, fin = bytearray(), plain[9:], False        # with room it goes on from there
+    pending, out, status, idle = plain, bytearray(), 0, 0
     while not status & api.STATUS_END_MARKER:
-        got, used, status = c.step(pending, 100, fin)
+        got, used, status = c.step(pending, 2, not pending)
+        idle = 0 if (got or used) else idle + 1
+        assert idle < 2, (len(out), len(pending), status)
+        assert len(got) <= 2
         out += got
         pending = pending[used:]
-        fin = not pending
     assert bytes(out) == comp
 
 
