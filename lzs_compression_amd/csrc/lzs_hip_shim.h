@@ -24,8 +24,20 @@ int lzs_hip_free(void *p);
 int lzs_hip_stream_create(void **stream);
 int lzs_hip_stream_destroy(void *stream);
 int lzs_hip_stream_sync(void *stream);
+int lzs_hip_event_create(void **event);              /* (no timing) */
+int lzs_hip_event_destroy(void *event);
+int lzs_hip_event_record(void *event, void *stream);
+int lzs_hip_event_sync(void *event);
+int lzs_hip_event_done(void *event);                 /* 1: complete, 0: not yet, < 0: minus a hipError_t */
+int lzs_hip_stream_wait_event(void *stream, void *event);
 int lzs_hip_host_malloc(void **p, size_t bytes);      /* pinned host memory */
+int lzs_hip_host_malloc_staging(void **p, size_t bytes);   /* pinned, hipHostMallocNonCoherent: pieces only the copy engines and the
+                                                             * host touch, handed over at events (56 instead of 35-39 GB/s on a quiet
+                                                             * device: tools/probes/pipe_copy_probe.hip) */
 int lzs_hip_host_free(void *p);
+/* `nwords` 32-bit words from device memory to PINNED host memory by a kernel on `stream` (not by a copy engine: an engine
+ * runs its queue in order, and a small copy waiting for a kernel would hold up the large copies queued behind it) */
+int lzs_hip_words_to_host(uint32_t *h_dst, const uint32_t *d_src, size_t nwords, void *stream);
 int lzs_hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_memset(void *dst, int value, size_t bytes, void *stream);

@@ -53,8 +53,6 @@ int lzs_backend_info(char *buf, size_t cap)
 }
 
 /* ------------------------------------------------------------------ device batches */
-typedef int (*launch_fn)(void *, size_t, uint32_t, uint32_t *, const void *, size_t,
-                         const uint32_t *, uint32_t, uint32_t, void *);
 
 static int check_batch(const char *who, const void *out_len, const void *in, size_t in_len,
                        size_t nblocks)
@@ -157,7 +155,7 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
 /* Each host thread keeps one HIP stream and four grow-only device buffers for the host-buffer
  * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
  * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
-#define KEEP_MAX ((size_t)256 << 20)
+#define KEEP_MAX ((size_t)640 << 20)
 
 
 static pthread_key_t  staging_key;
@@ -172,6 +170,9 @@ static void staging_destroy(void *p)
     if (st->stream) lzs_hip_stream_destroy(st->stream);
     if (st->host_box) lzs_hip_host_free(st->host_box);     /* pinned (lzs_incremental.c) */
     if (st->host_tab) lzs_hip_host_free(st->host_tab);
+    for (int i = 0; i < PIPE_STREAMS; i++) if (st->pipe_stream[i]) lzs_hip_stream_destroy(st->pipe_stream[i]);
+    for (int i = 0; i < PIPE_EVENTS; i++) if (st->pipe_event[i]) lzs_hip_event_destroy(st->pipe_event[i]);
+    for (int i = 0; i < 6; i++) if (st->pin[i]) lzs_hip_host_free(st->pin[i]);
     free(st);
 }
 
@@ -227,6 +228,10 @@ static void env_read(lzs_env_t *e)
     e->no_tails = get("LZS_NO_TAILS") != NULL;
     e->no_chunks = get("LZS_NO_CHUNKS") != NULL;
     e->overlap_off = get("LZS_HOST_SERIAL") != NULL;
+    v = get("LZS_COPY_THREADS"); e->copy_threads = v ? (int)strtol(v, NULL, 10) : 0;
+    e->pipe_trace = get("LZS_PIPE_TRACE") != NULL;
+    v = get("LZS_PIPE_GROUP"); e->pipe_group = v ? (int)strtol(v, NULL, 10) : 0;
+    v = get("LZS_PIPE_CHUNK_MB"); e->pipe_chunk_mb = v ? (int)strtol(v, NULL, 10) : 0;
     g_env_dev = get("LZS_DEV_ENV") != NULL;
 }
 
@@ -287,6 +292,12 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     if ((rc = require_device()) != LZS_OK) return rc;
 
     const uint32_t cap32 = out_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)out_cap;
+    /* a large batch: copy in, run and copy back overlapped, chunk by chunk (lzs_pipeline.c) */
+    {
+        int taken = 0;
+        rc = host_batch_pipelined(who, launch, out, out_stride, cap32, out_len, in, in_stride, in_len_each, in_len, nblocks, &taken);
+        if (taken || rc != LZS_OK) return rc;
+    }
     const size_t d_in_stride = round_up(in_len ? in_len : 1, 16);
     const size_t d_out_stride = round_up(cap32 ? cap32 : 1, 16);
     void *stream = NULL, *d_in = NULL, *d_out = NULL, *d_len = NULL, *d_in_len = NULL;
@@ -305,6 +316,9 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     if (!e && in_len_each) e = staging_reserve(st, BUF_INLEN, sizeof(uint32_t) * nblocks, &d_in_len);
     if (e) { rc = fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
 
+    const int debug = lzs_env()->stream_debug;
+    double t0 = debug ? now_ms() : 0, t1;
+#define STAGE(name) do { if (debug) { lzs_hip_stream_sync(stream); t1 = now_ms(); fprintf(stderr, "liblzs %s (%zu blocks): %s %.2f ms\n", who, nblocks, name, t1 - t0); t0 = t1; } } while (0)
     if (in_stride == d_in_stride && !in_len_each) {
         HIP_TRY(lzs_hip_h2d(d_in, in, d_in_stride * (nblocks - 1) + in_len, stream), "hipMemcpy H2D");
     } else if (nblocks < 16) {
@@ -332,6 +346,7 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
     if (in_len_each)
         HIP_TRY(lzs_hip_h2d(d_in_len, in_len_each, sizeof(uint32_t) * nblocks, stream), "hipMemcpy H2D");
 
+    STAGE("copy in");
     /* A small batch of blocks to decompress does not fill the device with one wavefront per block
      * (a wavefront takes 9 ms for a 64 KiB block, whatever the batch): then the blocks are cut
      * into segments for many wavefronts, like one long stream. */
@@ -354,6 +369,7 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
         HIP_TRY(lzs_hip_d2h(out_len, d_len, sizeof(uint32_t) * nblocks, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
     }
+    STAGE("kernel + lengths");
     /* copy back only what each block produced: nothing past out_len[b] is touched */
     if (nblocks < 16) {
         for (size_t b = 0; b < nblocks; b++)
@@ -398,7 +414,9 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
             if (len == 0) break;
         }
     }
+    STAGE("copy out + layout");
 #undef HIP_TRY
+#undef STAGE
 
 done:
     if (rc != LZS_OK && stream) lzs_hip_stream_sync(stream);   /* nothing of ours may still be in flight */

@@ -36,8 +36,14 @@ typedef struct {
     uint32_t stream_seg, dec_seg;   /* LZS_STREAM_SEG, LZS_DEC_SEG (0: by size) */
     int      stream_debug, no_marks, no_ones, verify_scan, no_tails, no_chunks;
     int      overlap_off;           /* LZS_HOST_SERIAL: host-buffer batches copy, run and copy back one after the other */
+    int      pipe_trace;            /* LZS_PIPE_TRACE (with LZS_STREAM_DEBUG): a line per step of those batches' pipeline */
+    int      pipe_group, pipe_chunk_mb;   /* LZS_PIPE_GROUP, LZS_PIPE_CHUNK_MB: chunks per launch / chunk size of those batches (0: the defaults) */
+    int      copy_threads;          /* LZS_COPY_THREADS: host threads that fill / empty the pinned pieces of a large batch (default 4) */
 } lzs_env_t;
 LZS_HIDDEN const lzs_env_t *lzs_env(void);
+
+#define PIPE_STREAMS 12
+#define PIPE_EVENTS  24
 
 /* per-thread staging (lzs_host.c): one HIP stream and grow-only device buffers per host thread */
 enum { BUF_IN, BUF_OUT, BUF_LEN, BUF_INLEN, BUF_AUX, BUF_KEEP, BUF_MARKS, BUF_COUNT };
@@ -48,12 +54,23 @@ typedef struct {
     uint8_t *host_box;              /* host side of the small incremental calls' single copies */
     void  *host_tab;                /* PINNED host memory for the per-segment tables of the stream paths: their */
     size_t host_tab_cap;            /* copies are small and many (five a round), and pageable ones cost ~150 us each */
+    /* the overlapped host-buffer batches (lzs_pipeline.c): copy-in, two compute and copy-out streams, events, pinned pieces */
+    void  *pipe_stream[PIPE_STREAMS];
+    void  *pipe_event[PIPE_EVENTS];
+    void  *pin[6];
+    size_t pin_cap[6];
 } staging_t;
 LZS_HIDDEN staging_t *staging_get(void);
 LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **out);   /* 0 or a hipError_t */
 LZS_HIDDEN void staging_trim(staging_t *st);
 LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes);   /* grow-only, pinned; NULL: out of memory */
 LZS_HIDDEN double now_ms(void);
+
+/* host-buffer batches with the three stages overlapped (lzs_pipeline.c); LZS_E_* or LZS_OK, *taken = 0: not this batch's route */
+typedef int (*launch_fn)(void *, size_t, uint32_t, uint32_t *, const void *, size_t, const uint32_t *, uint32_t, uint32_t, void *);
+LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *out, size_t out_stride, uint32_t cap32, uint32_t *out_len,
+                                    const uint8_t *in, size_t in_stride, const uint32_t *in_len_each, size_t in_len, size_t nblocks,
+                                    int *taken);
 
 /* thresholds of the one-shot calls */
 #define STREAM_MIN     6144u        /* shorter inputs are compressed by one workgroup (4 KiB: 0.109 ms alone, 0.127 in segments; 8 KiB: 0.167 / 0.127) */

@@ -84,10 +84,35 @@ int lzs_hip_describe(char *buf, size_t cap)
 int lzs_hip_malloc(void **p, size_t bytes) { return (int)hipMalloc(p, bytes ? bytes : 1); }
 int lzs_hip_free(void *p) { return (int)hipFree(p); }
 int lzs_hip_host_malloc(void **p, size_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault); }
+int lzs_hip_host_malloc_staging(void **p, size_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocNonCoherent); }
 int lzs_hip_host_free(void *p) { return (int)hipHostFree(p); }
+
+namespace {
+__global__ __launch_bounds__(256) void lzs_words_to_host_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+int lzs_hip_words_to_host(uint32_t *h_dst, const uint32_t *d_src, size_t nwords, void *stream)
+{
+    if (nwords == 0) return 0;
+    const size_t grid = (nwords + 255) / 256;
+    hipLaunchKernelGGL(lzs_words_to_host_kernel, dim3((unsigned)(grid < 64 ? grid : 64)), dim3(256), 0, (hipStream_t)stream, h_dst, d_src, nwords);
+    return (int)hipGetLastError();
+}
 int lzs_hip_stream_create(void **s) { return (int)hipStreamCreateWithFlags((hipStream_t *)s, hipStreamNonBlocking); }
 int lzs_hip_stream_destroy(void *s) { return (int)hipStreamDestroy((hipStream_t)s); }
 int lzs_hip_stream_sync(void *s) { return (int)hipStreamSynchronize((hipStream_t)s); }
+int lzs_hip_event_create(void **e) { return (int)hipEventCreateWithFlags((hipEvent_t *)e, hipEventDisableTiming); }
+int lzs_hip_event_destroy(void *e) { return (int)hipEventDestroy((hipEvent_t)e); }
+int lzs_hip_event_record(void *e, void *s) { return (int)hipEventRecord((hipEvent_t)e, (hipStream_t)s); }
+int lzs_hip_event_sync(void *e) { return (int)hipEventSynchronize((hipEvent_t)e); }
+int lzs_hip_event_done(void *e)
+{
+    const hipError_t r = hipEventQuery((hipEvent_t)e);
+    return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -(int)r);
+}
+int lzs_hip_stream_wait_event(void *s, void *e) { return (int)hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0); }
 int lzs_hip_h2d(void *d, const void *s, size_t n, void *st)
 {
     return n ? (int)hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st) : 0;

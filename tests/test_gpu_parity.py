@@ -1092,3 +1092,61 @@ def test_small_batch_in_device_memory_decompressed_in_segments():
             torch.cuda.synchronize()
             assert (out_len == ref_len.cpu().numpy()).all() and (out_len == cap).all()
             assert torch.equal(out[:, :cap], ref[:, :cap]) and torch.equal(out[:, :cap], x[:, :cap])
+
+
+def test_large_host_batches_take_the_overlapped_route_and_give_the_same_bytes(monkeypatch):
+    """lzs_compress_batch / lzs_decompress_batch on HOST buffers from a few hundred MiB on: copy in, kernel and copy
+    back run as a pipeline over chunks of blocks, host threads filling and emptying pinned pieces (lzs_pipeline.c).
+    Same results as the one-after-the-other route (LZS_HOST_SERIAL=1) and as the oracle -- uniform blocks, ragged
+    blocks in a strided array, a cut capacity, a last chunk of a few blocks, and from two host threads at once;
+    nothing past out_len[b] is touched."""
+    import threading
+    nb = 2 * 640 * 2 + 37                                   # four chunks and a short fifth
+    x = np.concatenate([workload.fill("text", nb - 600), workload.fill("lowent", 300), workload.fill("random", 300)])
+    rng = np.random.default_rng(5)
+    lens = rng.integers(1, 65537, nb).astype(np.uint32)
+    lens[::7] = 65536
+    cap = lzs.compressed_max(65536)
+
+    def run(serial, in_len_each, out_cap, fill):
+        if serial:
+            monkeypatch.setenv("LZS_HOST_SERIAL", "1")
+        else:
+            monkeypatch.delenv("LZS_HOST_SERIAL", raising=False)
+        out = np.full((nb, cap + 5), fill, dtype=np.uint8)
+        out_len = np.zeros(nb, dtype=np.uint32)
+        rc = lzs.lib().lzs_compress_batch(out.ctypes.data, cap + 5, out_cap, out_len.ctypes.data, x.ctypes.data, 65536,
+                                          in_len_each.ctypes.data if in_len_each is not None else None, 65536, nb)
+        assert rc == 0, lzs.last_error()
+        return out, out_len
+
+    for in_len_each, out_cap in ((None, cap), (lens, cap), (None, 30000)):
+        a, al = run(False, in_len_each, out_cap, 0xA5)
+        b, bl = run(True, in_len_each, out_cap, 0xA5)
+        assert np.array_equal(al, bl) and np.array_equal(a, b)                     # bytes AND the untouched fill behind them
+        for blk in (0, 639, 640, 1279, 1280, nb - 601, nb - 300, nb - 1):
+            n = int(in_len_each[blk]) if in_len_each is not None else 65536
+            want = O.compress(bytes(x[blk, :n]))[:out_cap]
+            assert int(al[blk]) == len(want) and a[blk, :len(want)].tobytes() == want, (blk, out_cap)
+            assert (a[blk, len(want):] == 0xA5).all()
+    # and back: ragged streams in a strided array, into exact-size slots
+    comp, clen = run(False, None, cap, 0)
+    back = np.full((nb, 65536 + 3), 0x5A, dtype=np.uint8)
+    back_len = np.zeros(nb, dtype=np.uint32)
+    rc = lzs.lib().lzs_decompress_batch(back.ctypes.data, 65536 + 3, 65536, back_len.ctypes.data, comp.ctypes.data, cap + 5,
+                                        clen.ctypes.data, cap, nb)
+    assert rc == 0 and (back_len == 65536).all() and np.array_equal(back[:, :65536], x) and (back[:, 65536:] == 0x5A).all()
+    # two host threads at once, each with its own streams and pinned pieces
+    results = [None, None]
+
+    def work(i):
+        out = np.zeros((nb, cap), dtype=np.uint8)
+        out_len = np.zeros(nb, dtype=np.uint32)
+        rc = lzs.lib().lzs_compress_batch(out.ctypes.data, cap, cap, out_len.ctypes.data, x.ctypes.data, 65536, None, 65536, nb)
+        results[i] = (rc, out_len.copy(), out[nb - 1, :out_len[nb - 1]].tobytes())
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for rc, out_len, last in results:
+        assert rc == 0 and np.array_equal(out_len, clen) and last == comp[nb - 1, :clen[nb - 1]].tobytes()
