@@ -174,7 +174,7 @@ int lzs_hip_chain_mode(void *stream, int *mode)
 }
 
 // ---- the ordering property once more, UNDER LOAD: lzs_hip_chain_mode() asks an idle device.  Beside the
-// first compress launch of a process on a device the same check runs again on a stream of its own -- 262144 patterns
+// first compress launch of a process on a device the same check runs again on a stream of its own -- 65536 patterns
 // this time, so that it overlaps the launch -- and whichever later launch finds it finished reads the verdict: a device
 // that fails it gets the order-independent CHAIN from then on, with a loud note (the launches before may be
 // off in their candidates' order: same format, possibly not the reference's bytes).
@@ -195,7 +195,7 @@ static void load_check_step(int dev, bool start)
             hipHostMalloc((void **)&c.h_bad, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) {
             *c.h_bad = 0;
             (void)hipMemsetAsync(c.d_bad, 0, sizeof(uint32_t), c.own);
-            hipLaunchKernelGGL(lzs_lds_order_check_kernel, dim3(512), dim3(256), 0, c.own, c.d_bad, 262144u);
+            hipLaunchKernelGGL(lzs_lds_order_check_kernel, dim3(512), dim3(256), 0, c.own, c.d_bad, 65536u);
             if (hipGetLastError() == hipSuccess &&
                 hipMemcpyAsync(c.h_bad, c.d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c.own) == hipSuccess &&
                 hipEventRecord(c.done, c.own) == hipSuccess)
@@ -203,12 +203,13 @@ static void load_check_step(int dev, bool start)
         }
     } else if (c.state == 1 && hipEventQuery(c.done) == hipSuccess) {
         if (*c.h_bad) {
-            fprintf(stderr, "liblzs: device %d applied same-address LDS exchanges out of lane order UNDER LOAD (%u lanes off in 262144 "
+            fprintf(stderr, "liblzs: device %d applied same-address LDS exchanges out of lane order UNDER LOAD (%u lanes off in 65536 "
                             "patterns beside a compress launch) although it passed the check when idle: switching to the "
                             "order-independent chain build; the launches so far may differ from the reference's bytes\n", dev, *c.h_bad);
             __atomic_store_n(&g_chain_mode[dev], 2, __ATOMIC_RELEASE);
         }
-        (void)hipFree(c.d_bad); (void)hipHostFree(c.h_bad); (void)hipEventDestroy(c.done); (void)hipStreamDestroy(c.own);
+        // (the four bytes, the event and the stream stay for the life of the process: releasing device memory waits for
+        // the device, and this runs inside a launch that promised to be asynchronous)
         __atomic_store_n(&c.state, 2, __ATOMIC_RELEASE);
     }
     pthread_mutex_unlock(&g_load_lock);

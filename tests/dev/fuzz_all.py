@@ -1,5 +1,7 @@
 """Dev aid: randomized cross-check of every host-visible path against the oracle for a given number
 of seconds (argv[1], default 300).  Prints the seed of any failure."""
+import os
+os.environ.setdefault("LZS_DEV_ENV", "1")      # this script flips the library's switches between calls (csrc/lzs_internal.h: lzs_env)
 import os, sys, time, random
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import numpy as np
@@ -158,6 +160,20 @@ def check_seed(seed):
         small = d[:rng.randint(0, min(len(d), 300000))]
         stage(seed, "inc encode", n=len(small))
         assert inc_encode(rng, small) == O.compress(small), "incremental encode"
+        tiny = small[:rng.randint(0, 2500)]
+        stage(seed, "simple encode, little room", n=len(tiny))
+        c = lzs.IncrementalCompressor(simple=True)
+        out_t, pos_t, pend_t, fin_t, st_t = bytearray(), 0, b"", False, 0
+        for _ in range(10 ** 6):
+            if not pend_t and not fin_t and pos_t < len(tiny):
+                pend_t = tiny[pos_t:pos_t + rng.randint(1, 400)]; pos_t += len(pend_t)
+            if not pend_t and pos_t >= len(tiny):
+                fin_t = True
+            got, used, st_t = c.step(pend_t, rng.randint(1, 14), fin_t)
+            out_t += got; pend_t = pend_t[used:]
+            if st_t & 4:
+                break
+        assert bytes(out_t) == O.compress(tiny), "lzs_simple_compress_incremental with 1..14 bytes of room"
         stage(seed, "inc decode", n=len(want))
         assert inc_decode(rng, want) == d, "incremental decode"
         ccap = rng.randint(0, len(want) + 3)
@@ -210,6 +226,28 @@ def check_seed(seed):
         back, m = lzs.decompress_batch(out, n, stride)
         for i, b in enumerate(blocks):
             assert back[i, :m[i]].tobytes() == b, "decompress_batch"
+        if seed % 40 == 7:
+            # a host batch large enough for the overlapped route (lzs_pipeline.c): ragged blocks in a strided array, every
+            # byte against the one-after-the-other route, a sample against the oracle, and back
+            nb = rng.randint(700, 1600)
+            stage(seed, "large host batch", nb=nb)
+            kinds = [make(rng, 70000) for _ in range(24)]
+            stride = 70000
+            arr = np.zeros((nb, stride), dtype=np.uint8); lens = np.zeros(nb, dtype=np.uint32)
+            for i in range(nb):
+                b = kinds[rng.randrange(len(kinds))]
+                b = b[:rng.randint(0, len(b))] if rng.random() < 0.5 else b
+                arr[i, :len(b)] = np.frombuffer(b, dtype=np.uint8); lens[i] = len(b)
+            os.environ.pop("LZS_HOST_SERIAL", None)
+            out, n = lzs.compress_batch(arr, lens)
+            os.environ["LZS_HOST_SERIAL"] = "1"
+            out2, n2 = lzs.compress_batch(arr, lens)
+            os.environ.pop("LZS_HOST_SERIAL", None)
+            assert np.array_equal(n, n2) and all(np.array_equal(out[i, :n[i]], out2[i, :n[i]]) for i in range(nb)), "large compress_batch: the two routes differ"
+            for i in [0, nb - 1] + [rng.randrange(nb) for _ in range(10)]:
+                assert out[i, :n[i]].tobytes() == O.compress(arr[i, :lens[i]].tobytes()), "large compress_batch vs oracle"
+            back, m = lzs.decompress_batch(out, n, stride)
+            assert np.array_equal(m, lens) and all(np.array_equal(back[i, :m[i]], arr[i, :lens[i]]) for i in range(nb)), "large decompress_batch"
     except Exception as e:
         import pickle
         os.makedirs(os.path.join(os.path.dirname(__file__), "..", "..", "gpurun_out"), exist_ok=True)
