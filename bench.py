@@ -424,6 +424,14 @@ def pick_device(args):
     return torch.device("cuda", local_rank % n)
 
 
+def hbm_needed(job_bytes: int, nb: int, cb: int, world: int, is_root: bool, slot_stride: int) -> int:
+    """Everything a rank of the config-5 job holds in HBM: the job's own buffers (`job_bytes`:
+    ShardedCompressJob.memory_needed), on the root also every rank's generated input, and the buffers of the
+    checks after the timed region (slots, a fresh compaction, the decoded blocks), plus 2 GiB of headroom."""
+    need = job_bytes + (world * nb * BLOCK if is_root else 0)
+    return need + cb * (2 * slot_stride + BLOCK + slot_stride) + (2 << 30)
+
+
 def check_ranges(lo: int, hi: int, check_every: int):
     """Which blocks of a chunk [lo, hi) the root compares with the CPU oracle: the first 1/check_every of
     them (one contiguous range of the gathered stream) and the last block; with check_every 1 all of them."""
@@ -460,9 +468,7 @@ def run_sharded(args, dist, rank: int, world: int, dev) -> dict:
     # against the HBM that is free; while it does not fit on EVERY rank the shard is halved (and the line says so)
     while True:
         cb = nb if args.no_overlap else min(nb, args.chunk_blocks)
-        need = ShardedCompressJob.memory_needed(nb, BLOCK, slot_stride, world, cb, rank == 0)
-        need += world * nb * BLOCK if rank == 0 else 0                         # `pieces`
-        need += cb * (2 * slot_stride + BLOCK + slot_stride) + (2 << 30)      # check buffers, decode output, headroom
+        need = hbm_needed(ShardedCompressJob.memory_needed(nb, BLOCK, slot_stride, world, cb, rank == 0), nb, cb, world, rank == 0, slot_stride)
         free, _total = torch.cuda.mem_get_info(dev)
         fits = torch.tensor([1 if free >= need else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(fits, op=dist.ReduceOp.MIN)

@@ -216,15 +216,17 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
     if (!e && in_len_each) e = staging_reserve(st, BUF_INLEN, sizeof(uint32_t) * nblocks, &d_in_len);
     if (!e) e = staging_reserve(st, BUF_KEEP, PIPE_SLOTS * dense_piece + 64, &d_dense);
     if (!e) e = staging_reserve(st, BUF_AUX, PIPE_SLOTS * sizeof(uint64_t) * (group + 1), &d_offs);
-    if (e) { rc = fail(LZS_E_NOMEM, "%s: device allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
+    /* (no room for the ring or the pinned pieces -- a small cgroup, many threads at once: nothing has been queued yet, the
+     * batch takes the one-after-the-other route, which needs neither) */
+    if (e) { *taken = 0; goto done; }
     uint8_t *pin_in[2], *pin_out[3], *pin_len = NULL;
     const size_t len_piece = sizeof(uint32_t) * group + sizeof(uint64_t);
     for (int i = 0; i < 2 && !e; i++) e = pin_reserve(st, PIPE_IN(i), chunk * d_in_stride, &pin_in[i]);
     for (int i = 0; i < 3 && !e; i++) e = pin_reserve(st, PIPE_OUT(i), chunk * d_out_stride, &pin_out[i]);
     if (!e) e = pin_reserve(st, 5, PIPE_SLOTS * len_piece, &pin_len);
-    if (e) { rc = fail(LZS_E_NOMEM, "%s: pinned host allocation failed: %s", who, lzs_hip_strerror(e)); goto done; }
+    if (e) { *taken = 0; goto done; }
     for (int i = 0; i < 3; i++) doff[i] = (uint64_t *)malloc(sizeof(uint64_t) * (chunk + 1));
-    if (!doff[0] || !doff[1] || !doff[2]) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+    if (!doff[0] || !doff[1] || !doff[2]) { *taken = 0; goto done; }
 
     for (int w = 1; w < P.nth; w++) {
         args[w].p = &P; args[w].w = w;

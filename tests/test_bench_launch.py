@@ -137,3 +137,21 @@ def test_a_supervisor_takes_its_worker_along_on_sigterm(tmp_path):
     else:
         os.kill(pid, signal.SIGKILL)                     # (this exact pid: the stub this test started)
         pytest.fail("the worker outlived its supervisor")
+
+
+def test_memory_plan_counts_the_roots_input_and_fits_288_gb_at_eight_ranks():
+    """The root of config 5 holds every rank's generated input and one worst-case region per rank next to its own
+    job buffers: at 8 ranks x 131072 blocks that is ~150 GB of the 288 -- it must be counted (the
+    pre-check used to leave `pieces` out) and it must fit; a peer needs a fraction of it; and a shard that is
+    halved needs about half."""
+    b = _bench_module()
+    sys.path.insert(0, ROOT)
+    from lzs_compression_amd.sharded_job import ShardedCompressJob
+    slot = (65536 + 8192 + 3 + 15) // 16 * 16
+    nb, cb, world = 131072, 8192, 8
+    root = b.hbm_needed(ShardedCompressJob.memory_needed(nb, 65536, slot, world, cb, True), nb, cb, world, True, slot)
+    peer = b.hbm_needed(ShardedCompressJob.memory_needed(nb, 65536, slot, world, cb, False), nb, cb, world, False, slot)
+    assert root > world * nb * 65536 + world * nb * slot            # the generated input AND the gathered regions
+    assert 140e9 < root < 200e9 < 288e9 and peer < 40e9 and peer < root / 4
+    half = b.hbm_needed(ShardedCompressJob.memory_needed(nb // 2, 65536, slot, world, cb, True), nb // 2, cb, world, True, slot)
+    assert 0.45 * root < half < 0.6 * root
