@@ -1136,6 +1136,27 @@ def test_large_host_batches_take_the_overlapped_route_and_give_the_same_bytes(mo
     rc = lzs.lib().lzs_decompress_batch(back.ctypes.data, 65536 + 3, 65536, back_len.ctypes.data, comp.ctypes.data, cap + 5,
                                         clen.ctypes.data, cap, nb)
     assert rc == 0 and (back_len == 65536).all() and np.array_equal(back[:, :65536], x) and (back[:, 65536:] == 0x5A).all()
+    # garbage and truncated streams, empty blocks: whatever the decoder makes of them, both routes make the same of it
+    junk = rng.integers(0, 256, (nb, 4000), dtype=np.uint8)
+    junk[::3, :2000] = comp[::3, :2000]                        # (some real streams, cut)
+    jl = rng.integers(0, 4001, nb).astype(np.uint32)
+    jl[::11] = 0
+    outs = []
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("LZS_HOST_SERIAL", "1")
+        else:
+            monkeypatch.delenv("LZS_HOST_SERIAL", raising=False)
+        o = np.full((nb, 70000), 0x33, dtype=np.uint8)
+        ol = np.zeros(nb, dtype=np.uint32)
+        rc = lzs.lib().lzs_decompress_batch(o.ctypes.data, 70000, 69000, ol.ctypes.data, junk.ctypes.data, 4000, jl.ctypes.data, 4000, nb)
+        assert rc == 0, lzs.last_error()
+        outs.append((o, ol))
+    monkeypatch.delenv("LZS_HOST_SERIAL", raising=False)
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0])
+    for blk in (0, 3, 11, nb - 1):
+        want = O.decompress(bytes(junk[blk, :jl[blk]]), 69000)
+        assert int(outs[0][1][blk]) == len(want) and outs[0][0][blk, :len(want)].tobytes() == want, blk
     # two host threads at once, each with its own streams and pinned pieces
     results = [None, None]
 
