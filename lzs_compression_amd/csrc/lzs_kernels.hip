@@ -322,9 +322,14 @@ static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, u
     // far apart that eight of them do not fit (strides of hundreds of MB) go one to a wavefront.
     const unsigned long long longest = d_in_len ? 0xC0000400ull : in_len;
     const uint32_t per_wave = (unsigned long long)in_stride * (kDecGroups - 1u) + longest < 0xFFFFFF00ull ? kDecGroups : 1u;
-    hipLaunchKernelGGL(lzs_decompress_blocks_grp_kernel, dim3((nblocks + per_wave - 1) / per_wave), dim3(64), 0,
-                       (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat, per_wave);
+    if (concat)
+        hipLaunchKernelGGL(lzs_decompress_blocks_grp_kernel<true>, dim3((nblocks + per_wave - 1) / per_wave), dim3(64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat, per_wave);
+    else
+        hipLaunchKernelGGL(lzs_decompress_blocks_grp_kernel<false>, dim3((nblocks + per_wave - 1) / per_wave), dim3(64), 0,
+                           (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, concat, per_wave);
     return (int)hipGetLastError();
 }
 

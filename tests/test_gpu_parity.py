@@ -440,6 +440,44 @@ def test_fuzz_decoder_on_garbage_vs_oracle():
             assert g == O.decompress(s, cap)
 
 
+def test_block_decoder_counts_bits_before_it_believes_them():
+    """The block decoder does not mask a stream's last word: whatever follows a stream in
+    its row -- here all-ones, random bytes, the continuation of the stream that was cut -- must never be
+    decoded, whatever token the cut falls into.  Streams of every kind cut at every length over a range,
+    rows wider than the streams with the tail poisoned, against the oracle on the cut stream."""
+    import torch
+    rng = np.random.default_rng(41)
+    text = bytes(workload.fill("text", 1).reshape(-1))[:3000]
+    kinds = [O.compress(text),                                                    # short matches and literals
+             O.compress(bytes(rng.integers(0, 256, 1500, dtype=np.uint8))),       # runs of literals
+             O.compress(b"ab" * 40 + b"\0" * 900 + text[:200] + b"x" * 300),      # length nibbles
+             O.compress(text[:700]) + O.compress(text[100:900])]                  # an end marker in the middle
+    cuts = []
+    for c in kinds:
+        cuts += [c[:n] for n in list(range(0, 140)) + list(range(len(c) - 40, len(c) + 1))]
+    stride = max(len(c) for c in cuts) + 24
+    for poison in ("ones", "random", "rest"):
+        arr = np.full((len(cuts), stride), 0xFF, dtype=np.uint8)
+        if poison == "random":
+            arr = rng.integers(0, 256, arr.shape, dtype=np.uint8)
+        for i, c in enumerate(cuts):
+            arr[i, :len(c)] = np.frombuffer(c, dtype=np.uint8)
+        if poison == "rest":                                                      # the stream goes on behind its stated length
+            k = 0
+            for c in kinds:
+                for n in list(range(0, 140)) + list(range(len(c) - 40, len(c) + 1)):
+                    m = min(len(c), stride)
+                    arr[k, :m] = np.frombuffer(c[:m], dtype=np.uint8)
+                    k += 1
+        lens = torch.tensor([len(c) for c in cuts], dtype=torch.int32, device="cuda")
+        for cap in (5000, 777):
+            out, out_len = lzs.decompress_blocks(torch.from_numpy(arr).cuda(), lens, cap)
+            torch.cuda.synchronize()
+            out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+            for i, c in enumerate(cuts):
+                assert out[i, :out_len[i]].tobytes() == O.decompress(c, cap), (poison, cap, i, len(c))
+
+
 def test_unaligned_strides_and_bases():
     """Any alignment of block bases / strides is accepted (slow path), same bytes."""
     rng = np.random.default_rng(3)
