@@ -431,12 +431,18 @@ int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, 
         static const int one_token = [] { return getenv("LZS_DEC_ONE_TOKEN") != nullptr; }();
         const bool two = !one_token && n != 0u && 4ull * n > cap && 10ull * n < 9ull * cap;
         const bool wide = !one_token && n != 0u && 10ull * n >= 9ull * cap;      // mostly literals: the 96-bit buffer
-#define LZS_LAUNCH_G8(T, W) hipLaunchKernelGGL((lzs_decode_stream_g8_kernel<T, W>), dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream, \
+#define LZS_LAUNCH_G8(T, W, C) hipLaunchKernelGGL((lzs_decode_stream_g8_kernel<T, W, C>), dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream, \
                                (uint8_t *)d_out, cap, d_origin, d_tainted, (const uint8_t *)d_in, n, in_extent, nseg, d_entry, d_out_start, seg, concat ? 1u : 0u, \
                                d_seg_base, d_seg_end, d_out_floor, d_out_limit)
-        if (two) LZS_LAUNCH_G8(true, false);
-        else if (wide) LZS_LAUNCH_G8(false, true);
-        else LZS_LAUNCH_G8(false, false);
+        if (concat) {
+            if (two) LZS_LAUNCH_G8(true, false, true);
+            else if (wide) LZS_LAUNCH_G8(false, true, true);
+            else LZS_LAUNCH_G8(false, false, true);
+        } else {
+            if (two) LZS_LAUNCH_G8(true, false, false);
+            else if (wide) LZS_LAUNCH_G8(false, true, false);
+            else LZS_LAUNCH_G8(false, false, false);
+        }
 #undef LZS_LAUNCH_G8
         return (int)hipGetLastError();
     }
