@@ -317,17 +317,19 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
                                            round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !lzs_env()->no_marks, seg, concat, NULL, NULL, stream), who);
-        HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
+        /* (exits and count lie one behind the other on both sides: one copy) */
+        HIP_TRY(lzs_hip_d2h(exits, d_exit, 2 * sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
-        HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         const uint32_t was = ndirty;
-        for (uint32_t k = 0; k < nseg; k++) if (dirty[k]) seen[k] = entry[k];   /* exits[k], count[k] belong to this entry */
         ndirty = 0;
+        if (dirty[0]) seen[0] = entry[0];                       /* exits[k], count[k] belong to this entry */
         dirty[0] = 0;
         int ended = 0;
         int settled = 1;            /* every segment before k has been walked from its final entry */
+        int host_made = 0;          /* exits / counts worked out here, not on the device */
         for (uint32_t k = 1; k < nseg; k++) {
+            if (dirty[k]) seen[k] = entry[k];
             uint32_t want = exits[k - 1];
             if (want & LZS_SEG_STOP) {
                 /* end marker or end of input before k -- believed only from a settled walk: one that
@@ -352,16 +354,15 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
                 exits[k] = (want & ~0xFFu) | (r + 4u * nibbles - seg * 8u);
                 count[k] = 15u * nibbles;
                 seen[k] = want;
+                host_made = 1;
                 continue;
             }
             dirty[k] = 1;
             ndirty++;
         }
         /* what the host worked out itself must survive the next round's copy back */
-        if (ndirty) {
-            HIP_TRY(lzs_hip_h2d(d_exit, exits, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
-            HIP_TRY(lzs_hip_h2d(d_count, count, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
-        }
+        if (ndirty && host_made)
+            HIP_TRY(lzs_hip_h2d(d_exit, exits, 2 * sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         if (debug) { t1 = now_ms(); fprintf(stderr, "liblzs stream decode: round %u scanned %u of %u segments in %.2f ms; %u to redo\n", round, was, nseg, t1 - t0, ndirty); t0 = t1; }
     }
     if (lzs_env()->verify_scan) {
@@ -430,9 +431,15 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         }
         for (; left && round < 250; round++) {
             HIP_TRY(lzs_hip_memset(d_counters + 1, 0, 4, stream), "hipMemset");
-            if (tails)
+            if (tails) {
+                /* three rounds to a look at the counter: a round on the tails is 30 - 130 us, the look costs as much */
                 HIP_TRY(lzs_hip_launch_resolve_tails(d_out, (uint32_t *)d_origin, before + produce, d_start, ndec, stride, round, d_counters + 1, stream), who);
-            else
+                for (int more = 0; more < 2; more++) {
+                    round++;
+                    HIP_TRY(lzs_hip_memset(d_counters + 1, 0, 4, stream), "hipMemset");
+                    HIP_TRY(lzs_hip_launch_resolve_tails(d_out, (uint32_t *)d_origin, before + produce, d_start, ndec, stride, round, d_counters + 1, stream), who);
+                }
+            } else
                 HIP_TRY(lzs_hip_launch_resolve_stream(d_out, (uint32_t *)d_origin, before + produce, round, d_counters + 1, had_tails, stream), who);
             HIP_TRY(lzs_hip_d2h(&left, d_counters + 1, 4, stream), "hipMemcpy D2H");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
