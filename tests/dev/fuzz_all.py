@@ -226,6 +226,32 @@ def check_seed(seed):
         back, m = lzs.decompress_batch(out, n, stride)
         for i, b in enumerate(blocks):
             assert back[i, :m[i]].tobytes() == b, "decompress_batch"
+        # streams cut anywhere, in rows whose tails are not zeros (the decoders do not mask a stream's last word):
+        # the host-buffer call (segments for so small a batch) and the eight-per-wavefront block decoder itself
+        stage(seed, "cut streams in poisoned rows")
+        import torch
+        srcs = [want] + [out[i, :n[i]].tobytes() for i in range(min(nb, 6))]
+        cuts_ = []
+        for _ in range(rng.randint(1, 48)):
+            c = srcs[rng.randrange(len(srcs))]
+            cuts_.append(c[:rng.randint(0, min(len(c), 9000))])
+        stride = max(1, max(len(c) for c in cuts_)) + rng.randint(0, 40)
+        rows = np.frombuffer(rng.randbytes(len(cuts_) * stride), dtype=np.uint8).reshape(len(cuts_), stride).copy()
+        if rng.random() < 0.3:
+            rows[:] = 0xFF
+        lens = np.zeros(len(cuts_), dtype=np.uint32)
+        for i, c in enumerate(cuts_):
+            rows[i, :len(c)] = np.frombuffer(c, dtype=np.uint8); lens[i] = len(c)
+        pcap = rng.choice((1, 300, 20000))
+        wants_ = [O.decompress(c, pcap) for c in cuts_]
+        back, m = lzs.decompress_batch(rows, lens, pcap)
+        for i, w in enumerate(wants_):
+            assert back[i, :m[i]].tobytes() == w, "decompress_batch of cut streams in poisoned rows"
+        bk, bm = lzs.decompress_blocks(torch.from_numpy(rows).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(), pcap)
+        torch.cuda.synchronize()
+        bk, bm = bk.cpu().numpy(), bm.cpu().numpy()
+        for i, w in enumerate(wants_):
+            assert bk[i, :bm[i]].tobytes() == w, "decompress_blocks of cut streams in poisoned rows"
         if seed % 40 == 7:
             # a host batch large enough for the overlapped route (lzs_pipeline.c): ragged blocks in a strided array, every
             # byte against the one-after-the-other route, a sample against the oracle, and back
