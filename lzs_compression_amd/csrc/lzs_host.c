@@ -232,6 +232,7 @@ static void env_read(lzs_env_t *e)
     e->pipe_trace = get("LZS_PIPE_TRACE") != NULL;
     v = get("LZS_PIPE_GROUP"); e->pipe_group = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_PIPE_CHUNK_MB"); e->pipe_chunk_mb = v ? (int)strtol(v, NULL, 10) : 0;
+    v = get("LZS_BATCH_SEG_MB"); e->batch_seg_mb = v ? (int)strtol(v, NULL, 10) : 0;
     g_env_dev = get("LZS_DEV_ENV") != NULL;
 }
 
@@ -293,7 +294,10 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
 
     const uint32_t cap32 = out_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)out_cap;
     /* a large batch: copy in, run and copy back overlapped, chunk by chunk (lzs_pipeline.c) */
-    {
+    const unsigned long long seg_extent = lzs_env()->batch_seg_mb > 0 ? (unsigned long long)lzs_env()->batch_seg_mb << 20 : BATCH_SEG_MAX_EXTENT;
+    const int by_segments = launch == lzs_hip_launch_decompress && cap32 && !lzs_env()->one_wave && nblocks <= BATCH_SEG_MAX_BLOCKS &&
+                            (unsigned long long)nblocks * round_up(cap32, 16) <= seg_extent;
+    if (!by_segments) {
         int taken = 0;
         rc = host_batch_pipelined(who, launch, out, out_stride, cap32, out_len, in, in_stride, in_len_each, in_len, nblocks, &taken);
         if (taken || rc != LZS_OK) return rc;
@@ -355,7 +359,7 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
         size_t total_in = 0;
         for (size_t b = 0; b < nblocks; b++) total_in += in_len_each ? in_len_each[b] : in_len;
         if (nblocks <= BATCH_SEG_MAX_BLOCKS && total_in >= STREAM_DEC_MIN && total_in / nblocks >= 1024u &&
-            (unsigned long long)nblocks * d_out_stride <= BATCH_SEG_MAX_EXTENT &&
+            (unsigned long long)nblocks * d_out_stride <= seg_extent &&
             (unsigned long long)nblocks * d_in_stride < 0xF0000000ull) {      /* segment tables hold 32-bit input offsets */
             rc = batch_decompress_segments(st, stream, who, d_out, d_out_stride, cap32, out_len, (uint32_t *)d_len, d_in, d_in_stride,
                                            in_len_each, (uint32_t)in_len, nblocks);
