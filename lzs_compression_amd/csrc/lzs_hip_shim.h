@@ -96,7 +96,7 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones /* or NULL */, uint32_t *d_marks, int compare,
                                uint32_t seg, int concat /* go on after end markers */,
-                               const uint32_t *d_seg_base, const uint32_t *d_seg_end /* or NULL, NULL */, void *stream);
+                               const uint32_t *d_seg_base, const uint32_t *d_seg_end /* or NULL, NULL */, uint32_t in_extent, void *stream);
 int lzs_hip_launch_decode_stream(void *d_out, uint32_t cap, uint32_t *d_origin, uint32_t *d_tainted,
                                  const void *d_in, uint32_t n, uint32_t in_extent /* readable bytes at d_in */,
                                  uint32_t nseg, const uint32_t *d_entry,

@@ -386,7 +386,7 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones, uint32_t *d_marks, int compare, uint32_t seg, int concat,
-                               const uint32_t *d_seg_base, const uint32_t *d_seg_end, void *stream)
+                               const uint32_t *d_seg_base, const uint32_t *d_seg_end, uint32_t in_extent, void *stream)
 {
     if (nseg == 0) return 0;
     static const int old_scan = [] { const char *v = getenv("LZS_SCAN"); return v && v[0] == 'w'; }();   // LZS_SCAN=wave: A/B
@@ -399,13 +399,13 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
         if (g8_scan)
             hipLaunchKernelGGL(lzs_scan_stream_g8_kernel<8>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
                                (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg,
-                               concat ? 1u : 0u, d_seg_base, d_seg_end);
+                               concat ? 1u : 0u, d_seg_base, d_seg_end, in_extent);
         else {
             if (d_marks && !compare)     // no marks yet (one store per lane and mark otherwise: 128 scattered words a segment)
                 (void)hipMemsetAsync(d_marks, 0xFF, (size_t)nseg * kScanMarkWords * sizeof(uint32_t), (hipStream_t)stream);
             hipLaunchKernelGGL(lzs_scan_stream_g8_kernel<1>, dim3((nseg + 63) / 64), dim3(64), 0, (hipStream_t)stream,
                                (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg,
-                               concat ? 1u : 0u, d_seg_base, d_seg_end);
+                               concat ? 1u : 0u, d_seg_base, d_seg_end, in_extent);
         }
         return (int)hipGetLastError();
     }

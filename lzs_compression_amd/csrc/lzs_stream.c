@@ -316,7 +316,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count,
-                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !lzs_env()->no_marks, seg, concat, NULL, NULL, stream), who);
+                                           round == 0 ? d_ones : NULL, (uint32_t *)d_marks, round != 0 && !lzs_env()->no_marks, seg, concat, NULL, NULL, (uint32_t)n, stream), who);
         /* (exits and count lie one behind the other on both sides: one copy) */
         HIP_TRY(lzs_hip_d2h(exits, d_exit, 2 * sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
@@ -372,7 +372,7 @@ LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in,
         memset(dirty, 1, nseg);
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
-        HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count, NULL, NULL, 0, seg, concat, NULL, NULL, stream), who);
+        HIP_TRY(lzs_hip_launch_scan_stream(d_in, (uint32_t)n, nseg, d_entry, d_dirty, d_exit, d_count, NULL, NULL, 0, seg, concat, NULL, NULL, (uint32_t)n, stream), who);
         HIP_TRY(lzs_hip_d2h(ex2, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(cn2, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
@@ -531,7 +531,7 @@ LZS_HIDDEN int batch_decompress_segments(staging_t *st, void *stream, const char
         HIP_TRY(lzs_hip_h2d(d_entry, entry, sizeof(uint32_t) * nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_h2d(d_dirty, dirty, nseg, stream), "hipMemcpy H2D");
         HIP_TRY(lzs_hip_launch_scan_stream(d_in, 0, nseg, d_entry, d_dirty, d_exit, d_count, round == 0 ? d_ones : NULL,
-                                           (uint32_t *)d_marks, round != 0, seg, 0, d_base, d_end, stream), who);
+                                           (uint32_t *)d_marks, round != 0, seg, 0, d_base, d_end, in_extent, stream), who);
         HIP_TRY(lzs_hip_d2h(exits, d_exit, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
         if (round == 0) HIP_TRY(lzs_hip_d2h(ones, d_ones, nseg, stream), "hipMemcpy D2H");
         HIP_TRY(lzs_hip_d2h(count, d_count, sizeof(uint32_t) * nseg, stream), "hipMemcpy D2H");
