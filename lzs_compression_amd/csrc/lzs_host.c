@@ -233,6 +233,7 @@ static void env_read(lzs_env_t *e)
     v = get("LZS_PIPE_GROUP"); e->pipe_group = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_PIPE_CHUNK_MB"); e->pipe_chunk_mb = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_BATCH_SEG_MB"); e->batch_seg_mb = v ? (int)strtol(v, NULL, 10) : 0;
+    v = get("LZS_PIPE_MIN_MB"); e->pipe_min_mb = v ? (int)strtol(v, NULL, 10) : 0;
     g_env_dev = get("LZS_DEV_ENV") != NULL;
 }
 

@@ -39,6 +39,7 @@ typedef struct {
     int      pipe_trace;            /* LZS_PIPE_TRACE (with LZS_STREAM_DEBUG): a line per step of those batches' pipeline */
     int      batch_seg_mb;          /* LZS_BATCH_SEG_MB: host-buffer batches to decompress go by segments up to this extent (0: the default) */
     int      pipe_group, pipe_chunk_mb;   /* LZS_PIPE_GROUP, LZS_PIPE_CHUNK_MB: chunks per launch / chunk size of those batches (0: the defaults) */
+    int      pipe_min_mb;           /* LZS_PIPE_MIN_MB: the smallest batch (MiB of the wider side) that takes the overlapped route (0: the default) */
     int      copy_threads;          /* LZS_COPY_THREADS: host threads that fill / empty the pinned pieces of a large batch (default 4) */
 } lzs_env_t;
 LZS_HIDDEN const lzs_env_t *lzs_env(void);

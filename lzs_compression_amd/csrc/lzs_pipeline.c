@@ -44,6 +44,8 @@
 #define PIPE_SLOTS   3              /* launches whose blocks, slots and dense piece are on the device at once: one being
                                      * copied in, one running, one being copied out */
 #define PIPE_GROUP_MAX 8            /* chunks per launch, at most */
+#define PIPE_MIN_MB  24             /* the smallest batch (MiB of the wider side) and ... */
+#define PIPE_MIN_BLOCKS 256         /* ... the fewest blocks that take this route (see host_batch_pipelined) */
 
 /* events */
 enum { EV_IN = 0,                   /* [2] H2D of chunk k has left pinned piece k & 1 */
@@ -161,10 +163,12 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
     /* chunks of about 45 MiB of the wider side (640 blocks of 64 KiB), at least 64 blocks; worth it from four chunks on */
     size_t chunk = ((size_t)(env->pipe_chunk_mb > 0 ? env->pipe_chunk_mb : 46) << 20) / widest;
     chunk = chunk < 64 ? 64 : chunk & ~(size_t)63;
-    /* From 48 MiB on (smaller batches of streams are decompressed in segments: lzs_host.c); a batch of fewer than four
-     * chunks is cut into four all the same: pinned pieces and host threads beat the runtime's path for pageable memory
-     * from there on (1024 blocks of 64 KiB: 9-28 ms -> see profiles/r04/hostbatch_r4.txt). */
-    if (env->overlap_off || !cap32 || nblocks < 256 || (unsigned long long)nblocks * widest < ((unsigned long long)48 << 20) ||
+    /* From 24 MiB on (batches of streams up to 32 MiB of output are decompressed in segments before this is asked:
+     * lzs_host.c); a batch of fewer than four chunks is cut into four all the same: pinned pieces and host threads beat
+     * the runtime's path for pageable memory from there on (1024 blocks of 64 KiB: 9-28 ms -> 3.3; 384 blocks: 2.3 -> 2.0,
+     * 512: 2.7 -> 2.2, equal at 256: profiles/r04/hostbatch_small_routes.txt). */
+    const unsigned long long least = (unsigned long long)(env->pipe_min_mb > 0 ? env->pipe_min_mb : PIPE_MIN_MB) << 20;
+    if (env->overlap_off || !cap32 || nblocks < PIPE_MIN_BLOCKS || (unsigned long long)nblocks * widest < least ||
         widest > ((size_t)4 << 20)) return LZS_OK;
     if (nblocks < 4 * chunk) chunk = ((nblocks + 3) / 4 + 63) & ~(size_t)63;
     const size_t K = (nblocks + chunk - 1) / chunk;

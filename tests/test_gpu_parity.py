@@ -1195,6 +1195,28 @@ def test_large_host_batches_take_the_overlapped_route_and_give_the_same_bytes(mo
     for blk in (0, 3, 11, nb - 1):
         want = O.decompress(bytes(junk[blk, :jl[blk]]), 69000)
         assert int(outs[0][1][blk]) == len(want) and outs[0][0][blk, :len(want)].tobytes() == want, blk
+    # the smallest batches that take this route (24 MiB: cut into four chunks of a hundred-odd blocks), ragged, both ways
+    for small in (350, 413, 650):
+        xs, ls = x[nb - 600 - 200: nb - 600 - 200 + small], lens[:small]
+        res = []
+        for serial in (False, True):
+            if serial:
+                monkeypatch.setenv("LZS_HOST_SERIAL", "1")
+            else:
+                monkeypatch.delenv("LZS_HOST_SERIAL", raising=False)
+            so = np.full((small, cap + 1), 0x77, dtype=np.uint8)
+            sl = np.zeros(small, dtype=np.uint32)
+            assert lzs.lib().lzs_compress_batch(so.ctypes.data, cap + 1, cap, sl.ctypes.data, xs.ctypes.data, 65536, ls.ctypes.data, 65536, small) == 0
+            sb = np.full((small, 65536), 0x11, dtype=np.uint8)
+            sbl = np.zeros(small, dtype=np.uint32)
+            assert lzs.lib().lzs_decompress_batch(sb.ctypes.data, 65536, 65536, sbl.ctypes.data, so.ctypes.data, cap + 1, sl.ctypes.data, cap, small) == 0
+            res.append((so, sl, sb, sbl))
+        monkeypatch.delenv("LZS_HOST_SERIAL", raising=False)
+        assert all(np.array_equal(p_, q_) for p_, q_ in zip(res[0], res[1])), small
+        assert np.array_equal(res[0][3], ls) and all(np.array_equal(res[0][2][i, :ls[i]], xs[i, :ls[i]]) for i in range(small))
+        for blk in (0, small // 2, small - 1):
+            want = O.compress(bytes(xs[blk, :ls[blk]]))
+            assert res[0][0][blk, :res[0][1][blk]].tobytes() == want
     # two host threads at once, each with its own streams and pinned pieces
     results = [None, None]
 
