@@ -79,7 +79,7 @@ int lzs_decompress_batch_device(void *d_out, size_t out_stride, size_t out_cap, 
  * the lengths in HOST memory (in_len_each may be NULL: every block in_len bytes; out_len receives
  * the results), and the call is synchronous: it runs on the calling thread's own stream, takes
  * scratch memory from the thread's staging and returns when d_out is complete.  Batches beyond
- * 32 MiB of output (or with blocks under 1 KiB on average) are handed to the one-wavefront-per-
+ * 64 MiB of output (or with blocks under 1 KiB on average) are handed to the one-wavefront-per-
  * block kernel.
  */
 int lzs_decompress_batch_device_sync(void *d_out, size_t out_stride, size_t out_cap, uint32_t *out_len,
@@ -133,7 +133,7 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
  * stages through device memory it allocates and frees itself and returns when the
  * results are in `out` / `out_len`.  in_len_each may be NULL (every block in_len bytes).
  * A batch to decompress that is too small to fill the device with a wavefront per block (up to
- * 32 MiB of output) is cut into segments for many wavefronts, block by block:
+ * 64 MiB of output) is cut into segments for many wavefronts, block by block:
  * 4 blocks of 64 KiB take 0.7 ms instead of 8.
  */
 int lzs_compress_batch(uint8_t *out, size_t out_stride, size_t out_cap, uint32_t *out_len,

@@ -252,6 +252,19 @@ LZS_HIDDEN const lzs_env_t *lzs_env(void)
  * default of 256 MiB per buffer for programs that compress large buffers over and over). */
 static size_t keep_max(void) { return lzs_env()->keep_max; }
 
+LZS_HIDDEN int staging_pin_reserve(staging_t *st, int which, size_t bytes, uint8_t **out)
+{
+    if (st->pin_cap[which] < bytes) {
+        if (st->pin[which]) { lzs_hip_host_free(st->pin[which]); st->pin[which] = NULL; st->pin_cap[which] = 0; }
+        const size_t want = (bytes + 65535u) & ~(size_t)65535u;
+        const int e = lzs_hip_host_malloc_staging(&st->pin[which], want);
+        if (e) { st->pin[which] = NULL; return e; }
+        st->pin_cap[which] = want;
+    }
+    *out = (uint8_t *)st->pin[which];
+    return 0;
+}
+
 LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes)
 {
     if (st->host_tab_cap < bytes) {
@@ -337,13 +350,20 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
          * (thousands of small copies cost more than the data) */
         size_t per = ((size_t)32 << 20) / d_in_stride;
         if (per == 0) per = 1;
-        bounce[0] = (uint8_t *)malloc(per * d_in_stride);
-        if (!bounce[0]) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+        /* (in one of the thread's pinned pieces: no pages to fault in call after call, and the copy engine reads it
+         * directly; plain memory only if there is no pinned memory to be had) */
+        const size_t lay = (nblocks < per ? nblocks : per) * d_in_stride;
+        uint8_t *piece_in = NULL;
+        if (staging_pin_reserve(st, 0, lay, &piece_in)) {
+            bounce[0] = (uint8_t *)malloc(lay);
+            if (!bounce[0]) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+            piece_in = bounce[0];
+        }
         for (size_t b0 = 0; b0 < nblocks; b0 += per) {
             const size_t nb = nblocks - b0 < per ? nblocks - b0 : per;
             for (size_t b = 0; b < nb; b++)
-                memcpy(bounce[0] + b * d_in_stride, in + (b0 + b) * in_stride, in_len_each ? in_len_each[b0 + b] : in_len);
-            HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + b0 * d_in_stride, bounce[0], nb * d_in_stride, stream), "hipMemcpy H2D");
+                memcpy(piece_in + b * d_in_stride, in + (b0 + b) * in_stride, in_len_each ? in_len_each[b0 + b] : in_len);
+            HIP_TRY(lzs_hip_h2d((uint8_t *)d_in + b0 * d_in_stride, piece_in, nb * d_in_stride, stream), "hipMemcpy H2D");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
         }
         free(bounce[0]); bounce[0] = NULL;
@@ -399,15 +419,21 @@ static int host_batch(const char *who, launch_fn launch, uint8_t *out, size_t ou
         HIP_TRY(lzs_hip_launch_compact(d_dense, (uint64_t *)d_offs, d_out, d_out_stride, (const uint32_t *)d_len,
                                        (uint32_t)nblocks, stream), who);
         const size_t piece = (size_t)32 << 20;
-        bounce[0] = (uint8_t *)malloc(total < piece ? total + 1 : piece);
-        bounce[1] = total > piece ? (uint8_t *)malloc(piece) : NULL;
-        if (!bounce[0] || (total > piece && !bounce[1])) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+        /* (pinned pieces of the thread, as on the way in) */
+        uint8_t *piece_out[2] = {NULL, NULL};
+        if (staging_pin_reserve(st, 2, total < piece ? total + 1 : piece, &piece_out[0]) ||
+            (total > piece && staging_pin_reserve(st, 3, piece, &piece_out[1]))) {
+            bounce[0] = (uint8_t *)malloc(total < piece ? total + 1 : piece);
+            bounce[1] = total > piece ? (uint8_t *)malloc(piece) : NULL;
+            if (!bounce[0] || (total > piece && !bounce[1])) { rc = fail(LZS_E_NOMEM, "%s: out of host memory", who); goto done; }
+            piece_out[0] = bounce[0]; piece_out[1] = bounce[1];
+        }
         size_t b = 0, within = 0;                              /* next block to lay out, bytes of it already done */
         for (size_t at = 0, k = 0; at < total || k == 0; k++) {
             const size_t len = total - at < piece ? total - at : piece;
-            HIP_TRY(lzs_hip_d2h(bounce[k & 1], (uint8_t *)d_dense + at, len, stream), "hipMemcpy D2H");
+            HIP_TRY(lzs_hip_d2h(piece_out[k & 1], (uint8_t *)d_dense + at, len, stream), "hipMemcpy D2H");
             HIP_TRY(lzs_hip_stream_sync(stream), "hipStreamSynchronize");
-            const uint8_t *src = bounce[k & 1];
+            const uint8_t *src = piece_out[k & 1];
             size_t left = len;
             while (left) {
                 while (b < nblocks && within == out_len[b]) { b++; within = 0; }

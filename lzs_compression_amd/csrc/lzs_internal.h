@@ -66,6 +66,10 @@ LZS_HIDDEN staging_t *staging_get(void);
 LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **out);   /* 0 or a hipError_t */
 LZS_HIDDEN void staging_trim(staging_t *st);
 LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes);   /* grow-only, pinned; NULL: out of memory */
+/* one of the thread's six pinned pieces (hipHostMallocNonCoherent: only the copy engines and the host touch them), grown
+ * to `bytes` if it is smaller; 0 or a HIP error.  lzs_pipeline.c: 0, 1 in, 2..4 out, 5 lengths; the one-after-the-other
+ * route of host_batch() lays ragged blocks out in 0 (in) and 2, 3 (out). */
+LZS_HIDDEN int staging_pin_reserve(staging_t *st, int which, size_t bytes, uint8_t **out);
 LZS_HIDDEN double now_ms(void);
 
 /* host-buffer batches with the three stages overlapped (lzs_pipeline.c); LZS_E_* or LZS_OK, *taken = 0: not this batch's route */
@@ -80,10 +84,12 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
 
 /* Batches up to this much output are decompressed in segments; larger ones fill the device with a
  * wavefront per block.  Measured (text, 64 KiB blocks, host buffers, ms; segments / wavefront per
- * block): 4 blocks 0.74 / 8.3, 64 blocks 1.5 / 8.5, 256 blocks 4.2 / 9.4, 512 blocks 11.4 / 13.4,
- * 1024 blocks 25.5 / 24.8. */
+ * block), round 2: 4 blocks 0.74 / 8.3, 64 blocks 1.5 / 8.5, 256 blocks 4.2 / 9.4, 512 blocks 11.4 / 13.4,
+ * 1024 blocks 25.5 / 24.8; round 4 (the segment decoder at six wavefronts per CU, the copies through pinned
+ * pieces; against the overlapped route with the block decoder): 768 blocks 6.2 / 8.6, 1024 blocks 7.3 / 8.9,
+ * 1536 blocks 9.9 / 10.2, 2048 blocks 12.4 / 12.4, 4096 blocks 22.2 / 17.8 (profiles/r04/hostbatch_small_routes.txt). */
 #define BATCH_SEG_MAX_BLOCKS 4096u
-#define BATCH_SEG_MAX_EXTENT ((unsigned long long)32 << 20)
+#define BATCH_SEG_MAX_EXTENT ((unsigned long long)64 << 20)
 
 /* one stream on the whole device (lzs_stream.c) */
 typedef struct {                    /* a piece of a stream for lzs_compress_incremental(): see stream_compress_piece() */

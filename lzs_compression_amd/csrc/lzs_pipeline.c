@@ -137,19 +137,6 @@ static void pipe_round(pipe_t *p)
     pthread_mutex_unlock(&p->mu);
 }
 
-static int pin_reserve(staging_t *st, int which, size_t bytes, uint8_t **out)
-{
-    if (st->pin_cap[which] < bytes) {
-        if (st->pin[which]) { lzs_hip_host_free(st->pin[which]); st->pin[which] = NULL; st->pin_cap[which] = 0; }
-        const size_t want = (bytes + 65535u) & ~(size_t)65535u;
-        const int e = lzs_hip_host_malloc_staging(&st->pin[which], want);
-        if (e) { st->pin[which] = NULL; return e; }
-        st->pin_cap[which] = want;
-    }
-    *out = (uint8_t *)st->pin[which];
-    return 0;
-}
-
 static size_t round16(size_t v) { return (v + 15u) & ~(size_t)15u; }
 
 LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *out, size_t out_stride, uint32_t cap32, uint32_t *out_len,
@@ -163,7 +150,7 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
     /* chunks of about 45 MiB of the wider side (640 blocks of 64 KiB), at least 64 blocks; worth it from four chunks on */
     size_t chunk = ((size_t)(env->pipe_chunk_mb > 0 ? env->pipe_chunk_mb : 46) << 20) / widest;
     chunk = chunk < 64 ? 64 : chunk & ~(size_t)63;
-    /* From 24 MiB on (batches of streams up to 32 MiB of output are decompressed in segments before this is asked:
+    /* From 24 MiB on (batches of streams up to 64 MiB of output are decompressed in segments before this is asked:
      * lzs_host.c); a batch of fewer than four chunks is cut into four all the same: pinned pieces and host threads beat
      * the runtime's path for pageable memory from there on (1024 blocks of 64 KiB: 9-28 ms -> 3.3; 384 blocks: 2.3 -> 2.0,
      * 512: 2.7 -> 2.2, equal at 256: profiles/r04/hostbatch_small_routes.txt). */
@@ -225,9 +212,9 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
     if (e) { *taken = 0; goto done; }
     uint8_t *pin_in[2], *pin_out[3], *pin_len = NULL;
     const size_t len_piece = sizeof(uint32_t) * group + sizeof(uint64_t);
-    for (int i = 0; i < 2 && !e; i++) e = pin_reserve(st, PIPE_IN(i), chunk * d_in_stride, &pin_in[i]);
-    for (int i = 0; i < 3 && !e; i++) e = pin_reserve(st, PIPE_OUT(i), chunk * d_out_stride, &pin_out[i]);
-    if (!e) e = pin_reserve(st, 5, PIPE_SLOTS * len_piece, &pin_len);
+    for (int i = 0; i < 2 && !e; i++) e = staging_pin_reserve(st, PIPE_IN(i), chunk * d_in_stride, &pin_in[i]);
+    for (int i = 0; i < 3 && !e; i++) e = staging_pin_reserve(st, PIPE_OUT(i), chunk * d_out_stride, &pin_out[i]);
+    if (!e) e = staging_pin_reserve(st, 5, PIPE_SLOTS * len_piece, &pin_len);
     if (e) { *taken = 0; goto done; }
     for (int i = 0; i < 3; i++) doff[i] = (uint64_t *)malloc(sizeof(uint64_t) * (chunk + 1));
     if (!doff[0] || !doff[1] || !doff[2]) { *taken = 0; goto done; }
