@@ -396,17 +396,17 @@ int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, cons
         if (d_all_ones)
             hipLaunchKernelGGL(lzs_all_ones_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                                (const uint8_t *)d_in, n, nseg, d_all_ones, seg, d_seg_base, d_seg_end);
-        if (g8_scan)
-            hipLaunchKernelGGL(lzs_scan_stream_g8_kernel<8>, dim3((nseg + 7) / 8), dim3(64), 0, (hipStream_t)stream,
-                               (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg,
-                               concat ? 1u : 0u, d_seg_base, d_seg_end, in_extent);
-        else {
+#define LZS_LAUNCH_SCAN(L, C, GRID) hipLaunchKernelGGL((lzs_scan_stream_g8_kernel<L, C>), dim3(GRID), dim3(64), 0, (hipStream_t)stream, \
+                               (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg, \
+                               concat ? 1u : 0u, d_seg_base, d_seg_end, in_extent)
+        if (g8_scan) {
+            if (concat) LZS_LAUNCH_SCAN(8, true, (nseg + 7) / 8); else LZS_LAUNCH_SCAN(8, false, (nseg + 7) / 8);
+        } else {
             if (d_marks && !compare)     // no marks yet (one store per lane and mark otherwise: 128 scattered words a segment)
                 (void)hipMemsetAsync(d_marks, 0xFF, (size_t)nseg * kScanMarkWords * sizeof(uint32_t), (hipStream_t)stream);
-            hipLaunchKernelGGL(lzs_scan_stream_g8_kernel<1>, dim3((nseg + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                               (const uint8_t *)d_in, n, nseg, d_entry, d_dirty, d_exit, d_count, d_marks, compare ? 1u : 0u, seg,
-                               concat ? 1u : 0u, d_seg_base, d_seg_end, in_extent);
+            if (concat) LZS_LAUNCH_SCAN(1, true, (nseg + 63) / 64); else LZS_LAUNCH_SCAN(1, false, (nseg + 63) / 64);
         }
+#undef LZS_LAUNCH_SCAN
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(lzs_scan_stream_kernel, dim3((nseg + 3) / 4), dim3(256), 0, (hipStream_t)stream,
