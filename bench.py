@@ -276,21 +276,53 @@ def self_launch(args, argv) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     print(f"bench.py: no WORLD_SIZE in the environment, launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     out_path = os.path.join(shared, "launch.stdout")
+    import signal
+
+    def end_group(proc, grace=5.0):
+        # the group this call started, nothing else: SIGTERM first (the supervisors take their GPU workers along), then SIGKILL
+        for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, None)):
+            if proc.poll() is not None:
+                break
+            try:
+                os.killpg(proc.pid, sig)
+            except OSError:
+                break
+            try:
+                proc.wait(timeout=wait)
+            except subprocess.TimeoutExpired:
+                pass
+
+    class Ended(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise Ended(signum)
+
     with open(out_path, "w+") as out:
-        # (a session of its own: on the deadline the whole group goes -- agent, supervisors and their workers)
+        # A session of its own: on the deadline the whole group goes -- agent, supervisors and their workers.  That also
+        # means a SIGTERM / SIGINT meant for THIS process (a `timeout 600 python bench.py`, the driver's own limit, Ctrl-C)
+        # no longer reaches them by itself: take the group along on those too, and on any exception.
         proc = subprocess.Popen(cmd, env=env, stdout=out, start_new_session=True)
+        old = {s: signal.signal(s, on_signal) for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
         try:
             rc = proc.wait(timeout=float(os.environ.get("LZS_BENCH_LAUNCH_DEADLINE", "3000")))
         except subprocess.TimeoutExpired:
-            import signal
-            try:
-                os.killpg(proc.pid, signal.SIGKILL)          # (the group this call started, nothing else)
-            except OSError:
-                pass
-            proc.wait()
+            end_group(proc, grace=0.0)
             rc = 124
+        except Ended as e:
+            print(f"bench.py: signal {e.args[0]}: ending the ranks this call launched", file=sys.stderr, flush=True)
+            end_group(proc)
+            rc = 128 + int(e.args[0])
+        except BaseException:
+            end_group(proc)
+            raise
+        finally:
+            for s, h in old.items():
+                signal.signal(s, h)
         out.seek(0)
         text = out.read()
+    if rc > 128:
+        return rc
     line = last_json_line(text)
     if line is None:
         sys.stderr.write(text[-4000:])

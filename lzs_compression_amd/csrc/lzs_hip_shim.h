@@ -35,8 +35,12 @@ int lzs_hip_host_malloc_staging(void **p, size_t bytes);   /* pinned, hipHostMal
                                                              * host touch, handed over at events (56 instead of 35-39 GB/s on a quiet
                                                              * device: tools/probes/pipe_copy_probe.hip) */
 int lzs_hip_host_free(void *p);
-/* `nwords` 32-bit words from device memory to PINNED host memory by a kernel on `stream` (not by a copy engine: an engine
- * runs its queue in order, and a small copy waiting for a kernel would hold up the large copies queued behind it) */
+/* Fetch and drop the runtime's sticky "last error" (a failed hipMalloc stays the answer of hipGetLastError() until it is
+ * fetched, and the launchers below return hipGetLastError() after their launch). */
+void lzs_hip_clear_error(void);
+/* `nwords` 32-bit words from device memory to PINNED, COHERENT host memory (lzs_hip_host_malloc) by a kernel on `stream`
+ * (not by a copy engine: an engine runs its queue in order, and a small copy waiting for a kernel would hold up the large
+ * copies queued behind it); the kernel ends with a system-scope fence */
 int lzs_hip_words_to_host(uint32_t *h_dst, const uint32_t *d_src, size_t nwords, void *stream);
 int lzs_hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_d2h(void *dst, const void *src, size_t bytes, void *stream);

@@ -195,8 +195,12 @@ LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **ou
     if (st->cap[which] < bytes) {
         if (st->buf[which]) { lzs_hip_free(st->buf[which]); st->buf[which] = NULL; st->cap[which] = 0; }
         size_t want = (bytes + 65535u) & ~(size_t)65535u;
+        /* (tests: LZS_STAGING_FAIL_MB=n makes a reservation above n MiB fail the way a full device fails it -- by a real
+         * hipMalloc that cannot succeed, so that the runtime's sticky last error is set as it would be) */
+        const int fail_mb = lzs_env()->staging_fail_mb;
+        if (fail_mb > 0 && want > ((size_t)fail_mb << 20)) want = (size_t)1 << 60;
         int e = lzs_hip_malloc(&st->buf[which], want);
-        if (e) return e;
+        if (e) { st->buf[which] = NULL; return e; }
         st->cap[which] = want;
     }
     *out = st->buf[which];
@@ -234,10 +238,11 @@ static void env_read(lzs_env_t *e)
     v = get("LZS_PIPE_CHUNK_MB"); e->pipe_chunk_mb = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_BATCH_SEG_MB"); e->batch_seg_mb = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_PIPE_MIN_MB"); e->pipe_min_mb = v ? (int)strtol(v, NULL, 10) : 0;
-    g_env_dev = get("LZS_DEV_ENV") != NULL;
+    v = get("LZS_STAGING_FAIL_MB"); e->staging_fail_mb = v ? (int)strtol(v, NULL, 10) : 0;
 }
 
-static void env_once(void) { env_read(&g_env); }
+/* (g_env_dev is written here and nowhere else: after pthread_once every thread only reads it -- ADVICE r04) */
+static void env_once(void) { env_read(&g_env); g_env_dev = get("LZS_DEV_ENV") != NULL; }
 
 LZS_HIDDEN const lzs_env_t *lzs_env(void)
 {
@@ -249,7 +254,7 @@ LZS_HIDDEN const lzs_env_t *lzs_env(void)
 }
 
 /* Buffers above the limit are released right after the call (LZS_KEEP_MAX_MB overrides the
- * default of 256 MiB per buffer for programs that compress large buffers over and over). */
+ * default of 640 MiB per buffer -- KEEP_MAX -- for programs that compress large buffers over and over). */
 static size_t keep_max(void) { return lzs_env()->keep_max; }
 
 LZS_HIDDEN int staging_pin_reserve(staging_t *st, int which, size_t bytes, uint8_t **out)
@@ -257,7 +262,10 @@ LZS_HIDDEN int staging_pin_reserve(staging_t *st, int which, size_t bytes, uint8
     if (st->pin_cap[which] < bytes) {
         if (st->pin[which]) { lzs_hip_host_free(st->pin[which]); st->pin[which] = NULL; st->pin_cap[which] = 0; }
         const size_t want = (bytes + 65535u) & ~(size_t)65535u;
-        const int e = lzs_hip_host_malloc_staging(&st->pin[which], want);
+        /* Pieces only the copy engines and the host touch are non-coherent (56 against 35-39 GB/s on a quiet device); the
+         * piece a KERNEL writes (PIN_LENGTHS: lzs_hip_words_to_host) is coherent host memory -- HIP does not promise that a
+         * kernel's stores to non-coherent host memory are visible to the host at an event. */
+        const int e = which == PIN_LENGTHS ? lzs_hip_host_malloc(&st->pin[which], want) : lzs_hip_host_malloc_staging(&st->pin[which], want);
         if (e) { st->pin[which] = NULL; return e; }
         st->pin_cap[which] = want;
     }

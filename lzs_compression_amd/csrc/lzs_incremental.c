@@ -460,8 +460,10 @@ size_t lzs_compress_incremental(LzsCompressParameters_t *p, bool add_end_marker)
 /* reference lzs-compression-simple.c: the low-memory compressor with the same output
  * (lzs.h:224-227).  Same calls, same stream; the 2112-byte block has no room to collect input or
  * to park output, so every call with >= 16 bytes to decide is a device call, and a call only takes
- * the input whose worst-case output (9 bits a byte, plus 8 bytes) fits outLength: with less than
- * 13 bytes of room nothing may be promised and the call returns NO_OUTPUT_BUFFER_SPACE at once. */
+ * the input whose worst-case output fits outLength and the block's nine spare bytes.  Any outLength
+ * >= 1 makes progress, like the reference's (lzs-compression-simple.c:435-647): with little room a
+ * call takes just the input that makes a few token starts decidable (their worst case is counted by
+ * tokens, not by bytes: DESIGN.md 3.7), and the final flush goes out in pieces that stop early. */
 size_t lzs_simple_compress_incremental(LzsSimpleCompressParameters_t *p, bool add_end_marker)
 {
     if (!p) return 0;

@@ -41,6 +41,7 @@ typedef struct {
     int      pipe_group, pipe_chunk_mb;   /* LZS_PIPE_GROUP, LZS_PIPE_CHUNK_MB: chunks per launch / chunk size of those batches (0: the defaults) */
     int      pipe_min_mb;           /* LZS_PIPE_MIN_MB: the smallest batch (MiB of the wider side) that takes the overlapped route (0: the default) */
     int      copy_threads;          /* LZS_COPY_THREADS: host threads that fill / empty the pinned pieces of a large batch (default 4) */
+    int      staging_fail_mb;       /* LZS_STAGING_FAIL_MB (tests): device reservations above this many MiB fail like a full device */
 } lzs_env_t;
 LZS_HIDDEN const lzs_env_t *lzs_env(void);
 
@@ -66,9 +67,11 @@ LZS_HIDDEN staging_t *staging_get(void);
 LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **out);   /* 0 or a hipError_t */
 LZS_HIDDEN void staging_trim(staging_t *st);
 LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes);   /* grow-only, pinned; NULL: out of memory */
-/* one of the thread's six pinned pieces (hipHostMallocNonCoherent: only the copy engines and the host touch them), grown
- * to `bytes` if it is smaller; 0 or a HIP error.  lzs_pipeline.c: 0, 1 in, 2..4 out, 5 lengths; the one-after-the-other
- * route of host_batch() lays ragged blocks out in 0 (in) and 2, 3 (out). */
+/* one of the thread's six pinned pieces (hipHostMallocNonCoherent: only the copy engines and the host touch them -- except
+ * PIN_LENGTHS, which a kernel writes and which is coherent), grown to `bytes` if it is smaller; 0 or a HIP error.
+ * lzs_pipeline.c: 0, 1 in, 2..4 out, 5 lengths; the one-after-the-other route of host_batch() lays ragged blocks out in
+ * 0 (in) and 2, 3 (out). */
+#define PIN_LENGTHS 5
 LZS_HIDDEN int staging_pin_reserve(staging_t *st, int which, size_t bytes, uint8_t **out);
 LZS_HIDDEN double now_ms(void);
 

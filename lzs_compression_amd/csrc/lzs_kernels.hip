@@ -86,11 +86,13 @@ int lzs_hip_free(void *p) { return (int)hipFree(p); }
 int lzs_hip_host_malloc(void **p, size_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault); }
 int lzs_hip_host_malloc_staging(void **p, size_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocNonCoherent); }
 int lzs_hip_host_free(void *p) { return (int)hipHostFree(p); }
+void lzs_hip_clear_error(void) { (void)hipGetLastError(); }
 
 namespace {
 __global__ __launch_bounds__(256) void lzs_words_to_host_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();                         // dst is host memory that the host reads at an event
 }
 }  // namespace
 int lzs_hip_words_to_host(uint32_t *h_dst, const uint32_t *d_src, size_t nwords, void *stream)

@@ -159,9 +159,13 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
         widest > ((size_t)4 << 20)) return LZS_OK;
     if (nblocks < 4 * chunk) chunk = ((nblocks + 3) / 4 + 63) & ~(size_t)63;
     const size_t K = (nblocks + chunk - 1) / chunk;
-    const size_t G = env->pipe_group > 0 && env->pipe_group <= PIPE_GROUP_MAX ? (size_t)env->pipe_group
-                   : launch == lzs_hip_launch_compress ? 2 : 8;            /* chunks per launch */
+    size_t G = env->pipe_group > 0 && env->pipe_group <= PIPE_GROUP_MAX ? (size_t)env->pipe_group
+             : launch == lzs_hip_launch_compress ? 2 : 8;                  /* chunks per launch ... */
+    if (G > K) G = K;                                                       /* ... of the chunks there are (a 1024-block
+                                                                             * decompress batch is ONE launch of four chunks, not a ring
+                                                                             * of three launches of eight) */
     const size_t J = (K + G - 1) / G;                                       /* launches */
+    const size_t slots = J < PIPE_SLOTS ? J : PIPE_SLOTS;                   /* launches' worth of device memory in the ring */
     if ((unsigned long long)G * chunk * d_out_stride > 0xF0000000ull) return LZS_OK;
     staging_t *st = staging_get();
     if (!st) return fail(LZS_E_NOMEM, "%s: out of host memory", who);
@@ -201,21 +205,23 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
     void *d_in = NULL, *d_out = NULL, *d_len = NULL, *d_in_len = NULL, *d_dense = NULL, *d_offs = NULL;
     const size_t group = G * chunk;                                         /* blocks per launch */
     const size_t dense_piece = group * d_out_stride + 32;
-    e = staging_reserve(st, BUF_IN, PIPE_SLOTS * group * d_in_stride, &d_in);
-    if (!e) e = staging_reserve(st, BUF_OUT, PIPE_SLOTS * group * d_out_stride, &d_out);
-    if (!e) e = staging_reserve(st, BUF_LEN, PIPE_SLOTS * sizeof(uint32_t) * group, &d_len);
+    e = staging_reserve(st, BUF_IN, slots * group * d_in_stride, &d_in);
+    if (!e) e = staging_reserve(st, BUF_OUT, slots * group * d_out_stride, &d_out);
+    if (!e) e = staging_reserve(st, BUF_LEN, slots * sizeof(uint32_t) * group, &d_len);
     if (!e && in_len_each) e = staging_reserve(st, BUF_INLEN, sizeof(uint32_t) * nblocks, &d_in_len);
-    if (!e) e = staging_reserve(st, BUF_KEEP, PIPE_SLOTS * dense_piece + 64, &d_dense);
-    if (!e) e = staging_reserve(st, BUF_AUX, PIPE_SLOTS * sizeof(uint64_t) * (group + 1), &d_offs);
+    if (!e) e = staging_reserve(st, BUF_KEEP, slots * dense_piece + 64, &d_dense);
+    if (!e) e = staging_reserve(st, BUF_AUX, slots * sizeof(uint64_t) * (group + 1), &d_offs);
     /* (no room for the ring or the pinned pieces -- a small cgroup, many threads at once: nothing has been queued yet, the
-     * batch takes the one-after-the-other route, which needs neither) */
-    if (e) { *taken = 0; goto done; }
+     * batch takes the one-after-the-other route, which needs neither.  The runtime keeps a failed allocation as its "last
+     * error" until somebody fetches it, and every launcher returns the last error after its launch: fetch it here, or the
+     * route that is to save the call reports this out-of-memory as its own -- ADVICE r04) */
+    if (e) { lzs_hip_clear_error(); *taken = 0; goto done; }
     uint8_t *pin_in[2], *pin_out[3], *pin_len = NULL;
     const size_t len_piece = sizeof(uint32_t) * group + sizeof(uint64_t);
     for (int i = 0; i < 2 && !e; i++) e = staging_pin_reserve(st, PIPE_IN(i), chunk * d_in_stride, &pin_in[i]);
     for (int i = 0; i < 3 && !e; i++) e = staging_pin_reserve(st, PIPE_OUT(i), chunk * d_out_stride, &pin_out[i]);
-    if (!e) e = staging_pin_reserve(st, 5, PIPE_SLOTS * len_piece, &pin_len);
-    if (e) { *taken = 0; goto done; }
+    if (!e) e = staging_pin_reserve(st, PIN_LENGTHS, slots * len_piece, &pin_len);
+    if (e) { lzs_hip_clear_error(); *taken = 0; goto done; }
     for (int i = 0; i < 3; i++) doff[i] = (uint64_t *)malloc(sizeof(uint64_t) * (chunk + 1));
     if (!doff[0] || !doff[1] || !doff[2]) { *taken = 0; goto done; }
 

@@ -11,9 +11,10 @@ mode = os.environ.get("LZS_STUB_MODE", "ok")
 shared = os.environ["LZS_BENCH_DIR"]
 assert os.path.isdir(shared)
 if os.environ.get("LZS_STUB_PIDFILE"):
-    with open(os.environ["LZS_STUB_PIDFILE"] + ".tmp", "w") as f:
-        f.write(str(os.getpid()))
-    os.replace(os.environ["LZS_STUB_PIDFILE"] + ".tmp", os.environ["LZS_STUB_PIDFILE"])
+    for name in (os.environ["LZS_STUB_PIDFILE"], os.environ["LZS_STUB_PIDFILE"] + f".rank{rank}"):   # (the plain name: one-rank tests)
+        with open(f"{name}.tmp{os.getpid()}", "w") as f:
+            f.write(str(os.getpid()))
+        os.replace(f"{name}.tmp{os.getpid()}", name)
 if role == "job":
     if mode == "fail_rank1" and rank == 1:
         sys.exit(3)

@@ -139,6 +139,33 @@ def test_a_supervisor_takes_its_worker_along_on_sigterm(tmp_path):
         pytest.fail("the worker outlived its supervisor")
 
 
+def test_the_launcher_takes_its_ranks_along_on_sigterm(tmp_path):
+    """`python bench.py --gpus 2` starts its ranks as a session of their own, so a SIGTERM meant for the launcher (a
+    `timeout 600 python bench.py`, the driver's limit, Ctrl-C) does not reach them by itself: the launcher must end the
+    group -- agent, supervisors and the workers on the GPUs -- before it leaves."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LZS_BENCH_ROLE", "LZS_BENCH_DIR")}
+    env.update(LZS_BENCH_WORKER_CMD=STUB, LZS_STUB_MODE="hang_rank0", LZS_STUB_PIDFILE=str(tmp_path / "worker.pid"))
+    launcher = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t_end = time.time() + 120
+    while not (tmp_path / "worker.pid.rank0").exists() and time.time() < t_end:
+        time.sleep(0.05)
+    pid = int((tmp_path / "worker.pid.rank0").read_text())          # the rank that hangs "on its GPU"
+    launcher.send_signal(signal.SIGTERM)
+    assert launcher.wait(timeout=60) == 128 + signal.SIGTERM
+    for _ in range(200):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, signal.SIGKILL)                     # (this exact pid: the stub this test started)
+        pytest.fail("a worker outlived the launcher")
+
+
 def test_memory_plan_counts_the_roots_input_and_fits_288_gb_at_eight_ranks():
     """The root of config 5 holds every rank's generated input and one worst-case region per rank next to its own
     job buffers: at 8 ranks x 131072 blocks that is ~150 GB of the 288 -- it must be counted (the
