@@ -173,6 +173,7 @@ static void staging_destroy(void *p)
     for (int i = 0; i < PIPE_STREAMS; i++) if (st->pipe_stream[i]) lzs_hip_stream_destroy(st->pipe_stream[i]);
     for (int i = 0; i < PIPE_EVENTS; i++) if (st->pipe_event[i]) lzs_hip_event_destroy(st->pipe_event[i]);
     for (int i = 0; i < 6; i++) if (st->pin[i]) lzs_hip_host_free(st->pin[i]);
+    free(st->hostcodec);
     free(st);
 }
 
@@ -239,6 +240,7 @@ static void env_read(lzs_env_t *e)
     v = get("LZS_BATCH_SEG_MB"); e->batch_seg_mb = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_PIPE_MIN_MB"); e->pipe_min_mb = v ? (int)strtol(v, NULL, 10) : 0;
     v = get("LZS_STAGING_FAIL_MB"); e->staging_fail_mb = v ? (int)strtol(v, NULL, 10) : 0;
+    v = get("LZS_ROUTE"); e->route = !v ? LZS_ROUTE_AUTO : (v[0] == 'd' ? LZS_ROUTE_DEVICE : (v[0] == 'h' ? LZS_ROUTE_HOST : LZS_ROUTE_AUTO));
 }
 
 /* (g_env_dev is written here and nowhere else: after pthread_once every thread only reads it -- ADVICE r04) */
@@ -562,8 +564,32 @@ static size_t long_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_
     return made;
 }
 
+/* The small calls' host route (lzs_hostcodec.c): taken BY SIZE on a box that has its device -- require_device() comes
+ * first, the library still fails loudly without one -- or by name (LZS_ROUTE=host). */
+static int small_call_on_host(const char *who, size_t n, size_t crossover)
+{
+    if (!route_on_host(n, crossover)) return 0;
+    if (lzs_env()->route != LZS_ROUTE_HOST && require_device() != LZS_OK) {
+        fprintf(stderr, "liblzs: %s failed: %s\n", who, tls_error);
+        return -1;
+    }
+    return 1;
+}
+
 size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
+    if ((a_pOutData || !a_outBufferSize) && (a_pInData || !a_inLen)) {
+        tls_error[0] = 0;
+        const int h = small_call_on_host("lzs_compress", a_inLen, HOST_COMPRESS_MAX);
+        if (h < 0) return 0;
+        if (h && a_inLen <= 0x40000000u) {
+            const size_t got = hostcodec_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+            if (got != SIZE_MAX) return got;
+            fail(LZS_E_NOMEM, "lzs_compress: out of host memory");
+            fprintf(stderr, "liblzs: lzs_compress failed: %s\n", tls_error);
+            return 0;
+        }
+    }
     if (a_inLen > LZS_BLOCK_MAX && a_pOutData && a_pInData) {
         tls_error[0] = 0;
         return long_compress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
@@ -575,6 +601,12 @@ size_t lzs_compress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *
 
 size_t lzs_decompress(uint8_t *a_pOutData, size_t a_outBufferSize, const uint8_t *a_pInData, size_t a_inLen)
 {
+    if ((a_pOutData || !a_outBufferSize) && (a_pInData || !a_inLen)) {
+        tls_error[0] = 0;
+        const int h = small_call_on_host("lzs_decompress", a_inLen, HOST_DECOMPRESS_MAX);
+        if (h < 0) return 0;
+        if (h) return hostcodec_decompress(a_pOutData, a_outBufferSize, a_pInData, a_inLen);
+    }
     /* a stream longer than one launch takes, or one that may fill more than the 32-bit positions of
      * the device reach (a length nibble stands for up to 15 bytes: 30 bytes of output per byte) */
     if (a_pOutData && a_pInData &&

@@ -42,6 +42,34 @@ void lzs_decompress_init(LzsDecompressParameters_t *p)
     memset(p->reserved_, 0, sizeof(p->reserved_));
 }
 
+/* The call on the host route (lzs_hostcodec.c): the one wavefront's work -- same state, same stop rules -- done by the
+ * calling thread, straight from the caller's input into the caller's output. */
+static size_t dec_incremental_host(LzsDecompressParameters_t *p, dec_priv_t *pv)
+{
+    size_t made = 0;
+    lzs_dec_resume_t h;
+    for (;;) {
+        const size_t take = p->inLength < ((size_t)1 << 30) ? p->inLength : ((size_t)1 << 30);
+        const size_t cap = p->outLength < 0xF0000000u ? p->outLength : 0xF0000000u;
+        h.bitq = pv->bitq; h.qlen = pv->qlen; h.off = pv->off; h.rem = pv->rem;
+        h.extended = pv->extended; h.hist_len = pv->hist_len;
+        h.in_used = h.out_made = h.status = h.reserved = 0;
+        memcpy(h.hist, pv->hist, pv->hist_len);
+        hostcodec_decode_resume(&h, p->inPtr, (uint32_t)take, p->outPtr, (uint32_t)cap);
+        pv->bitq = h.bitq; pv->qlen = (uint8_t)h.qlen; pv->off = (uint16_t)h.off; pv->rem = (uint8_t)h.rem;
+        pv->extended = (uint8_t)h.extended; pv->hist_len = (uint16_t)h.hist_len;
+        memcpy(pv->hist, h.hist, h.hist_len);
+        p->inPtr += h.in_used;   p->inLength -= h.in_used;
+        p->outPtr += h.out_made; p->outLength -= h.out_made;
+        made += h.out_made;
+        /* stopped only because of this loop's own limits: go on */
+        if ((h.status & LZS_INC_INPUT_STARVED) && p->inLength) continue;
+        if ((h.status & LZS_INC_NO_OUTPUT_SPACE) && p->outLength) continue;
+        p->status = (uint8_t)h.status;
+        return made;
+    }
+}
+
 size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
 {
     const char *who = "lzs_decompress_incremental";
@@ -61,6 +89,11 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     if ((p->inLength && !p->inPtr) || (p->outLength && !p->outPtr)) {
         fail(LZS_E_ARG, "%s: NULL buffer", who);
         goto failed;                /* terminal like every other failure: a loop that never looks at ERROR ends */
+    }
+    /* a small piece: the host route (by size on a box with its device -- require_device() first -- or by name) */
+    if (route_on_host(p->inLength, INC_DEC_HOST_MAX)) {
+        if (lzs_env()->route != LZS_ROUTE_HOST && require_device() != LZS_OK) goto failed;
+        return dec_incremental_host(p, pv);
     }
     if (require_device() != LZS_OK) goto failed;
     st = staging_get();
@@ -313,7 +346,7 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
         goto failed;                /* terminal like every other failure: a loop that never looks at ERROR ends */
     }
     /* no device, no stream: say so at the first call, not when the collected input is flushed */
-    if (require_device() != LZS_OK) goto failed;
+    if (lzs_env()->route != LZS_ROUTE_HOST && require_device() != LZS_OK) goto failed;
     /* output still waiting from the call before goes first (:574-588) */
     if (s->pend_pos < s->pend_len) {
         const size_t have = s->pend_len - s->pend_pos;
@@ -391,8 +424,15 @@ static size_t inc_compress_core(enc_core_t *s, bool add_end_marker, const char *
         tmp = (uint8_t *)malloc(cap);
         if (!tmp) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
         int rc = LZS_OK;
-        const size_t got = stream_compress_piece(tmp, cap, *s->inPtr, n, 0, &rc, &pc);
-        if (rc != LZS_OK) goto failed_quiet;
+        /* a piece with little to decide: the host route (lzs_hostcodec.c), same contract */
+        size_t got;
+        if (route_on_host(n - c0, INC_ENC_HOST_MAX)) {
+            got = hostcodec_compress_piece(tmp, cap, *s->inPtr, n, &pc);
+            if (got == SIZE_MAX) { fail(LZS_E_NOMEM, "%s: out of host memory", who); goto failed; }
+        } else {
+            got = stream_compress_piece(tmp, cap, *s->inPtr, n, 0, &rc, &pc);
+            if (rc != LZS_OK) goto failed_quiet;
+        }
         const size_t whole = last ? got : (size_t)(pc.nbits / 8);
         if (whole > got || whole > room || pc.c_exit > n || pc.c_exit < c0 || (last ? pc.c_exit != n : n - pc.c_exit > INC_UNDECIDED)) {
             fail(LZS_E_HIP, "%s: inconsistent state from the device (piece of %zu bytes from %u: %zu bytes out, %llu bits, ends at %u, room %zu)",

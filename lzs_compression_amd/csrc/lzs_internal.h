@@ -42,6 +42,8 @@ typedef struct {
     int      pipe_min_mb;           /* LZS_PIPE_MIN_MB: the smallest batch (MiB of the wider side) that takes the overlapped route (0: the default) */
     int      copy_threads;          /* LZS_COPY_THREADS: host threads that fill / empty the pinned pieces of a large batch (default 4) */
     int      staging_fail_mb;       /* LZS_STAGING_FAIL_MB (tests): device reservations above this many MiB fail like a full device */
+    int      route;                 /* LZS_ROUTE: 0 by size (the default), 1 "device": every call on the device, 2 "host": the small
+                                     * calls' host route for every size it can take, and no device needed (lzs_hostcodec.c) */
 } lzs_env_t;
 LZS_HIDDEN const lzs_env_t *lzs_env(void);
 
@@ -62,6 +64,7 @@ typedef struct {
     void  *pipe_event[PIPE_EVENTS];
     void  *pin[6];
     size_t pin_cap[6];
+    void  *hostcodec;               /* the host route's match-finder tables (lzs_hostcodec.c), made on first use */
 } staging_t;
 LZS_HIDDEN staging_t *staging_get(void);
 LZS_HIDDEN int staging_reserve(staging_t *st, int which, size_t bytes, void **out);   /* 0 or a hipError_t */
@@ -80,6 +83,24 @@ typedef int (*launch_fn)(void *, size_t, uint32_t, uint32_t *, const void *, siz
 LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *out, size_t out_stride, uint32_t cap32, uint32_t *out_len,
                                     const uint8_t *in, size_t in_stride, const uint32_t *in_len_each, size_t in_len, size_t nblocks,
                                     int *taken);
+
+/* ---- the host route of the small calls (lzs_hostcodec.c).  Which call takes it: */
+#define LZS_ROUTE_AUTO 0
+#define LZS_ROUTE_DEVICE 1
+#define LZS_ROUTE_HOST 2
+/* the crossovers, measured on the GPU box (profiles/r05/route_crossover.txt): below them one host core is faster than a
+ * launch and its wait */
+#define HOST_COMPRESS_MAX    16384u     /* lzs_compress(): input bytes */
+#define HOST_DECOMPRESS_MAX  65536u     /* lzs_decompress(): compressed bytes */
+#define INC_DEC_HOST_MAX     65536u     /* lzs_decompress_incremental(): a call's input bytes */
+#define INC_ENC_HOST_MAX     32768u     /* lzs_*compress_incremental(): bytes a piece has to decide */
+static inline int route_on_host(size_t n, size_t crossover)
+{
+    const int r = lzs_env()->route;
+    return r == LZS_ROUTE_HOST || (r == LZS_ROUTE_AUTO && n <= crossover);
+}
+LZS_HIDDEN size_t hostcodec_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n);      /* SIZE_MAX: out of memory */
+LZS_HIDDEN size_t hostcodec_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n);
 
 /* thresholds of the one-shot calls */
 #define STREAM_MIN     6144u        /* shorter inputs are compressed by one workgroup (4 KiB: 0.109 ms alone, 0.127 in segments; 8 KiB: 0.167 / 0.127) */
@@ -119,6 +140,8 @@ typedef struct {                    /* a piece of a stream for lzs_decompress_in
     uint32_t next_entry;        /* state word at the start of segment segs_done */
 } dec_piece_t;
 LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, piece_t *pc);
+LZS_HIDDEN size_t hostcodec_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, piece_t *pc);   /* the same on the host; SIZE_MAX: out of memory */
+LZS_HIDDEN void hostcodec_decode_resume(lzs_dec_resume_t *st, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap);   /* lzs_decode_resume_kernel's contract */
 LZS_HIDDEN size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status);
 LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, int concat,
                                     dec_piece_t *dp);

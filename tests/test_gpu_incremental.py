@@ -17,18 +17,28 @@ from conftest import golden_bytes
 import lzs_compression_amd as lzs
 from lzs_compression_amd import api, workload
 
-pytestmark = pytest.mark.gpu
-
 torch = pytest.importorskip("torch")
 O = oracle.oracle()
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 
 
-@pytest.fixture(scope="module", autouse=True)
-def _need_gpu():
-    if not torch.cuda.is_available():
-        pytest.fail("these tests need a GPU (no fallback exists)")
+# Every test here runs on BOTH routes of the small calls: "device" -- LZS_ROUTE=device, every call on
+# the GPU whatever its size, the parity tests proper (-m gpu) -- and "host" -- LZS_ROUTE=host, the calling thread's own
+# codec (csrc/lzs_hostcodec.c) for every size, which needs no device and therefore runs in the CPU suite too.  The default
+# (by size) is a mix of the two that switches at the crossovers; tests/test_routes.py covers the switch itself.
+@pytest.fixture(autouse=True, params=[pytest.param("device", marks=pytest.mark.gpu), "host"])
+def route(request, monkeypatch):
+    if request.param == "device" and not torch.cuda.is_available():
+        pytest.fail("the device route needs a GPU (it has no fallback)")
+    monkeypatch.setenv("LZS_ROUTE", request.param)
+    return request.param
+
+
+def device_only(route):
+    """For a test of what only the device route does (segments, many wavefronts)."""
+    if route != "device":
+        pytest.skip("a property of the device route")
 
 
 def _decode(stream, in_chunks, out_chunks, stop_at_markers=1):
@@ -261,7 +271,8 @@ def test_encode_random_pieces_equals_one_shot(kind):
         assert got == want, (kind, lo, hi, len(got), len(want))
 
 
-def test_encode_one_big_call_uses_many_segments():
+def test_encode_one_big_call_uses_many_segments(route):
+    device_only(route)
     plain = _sample("text", 3 << 20)
     got, _ = _encode(plain, _const(len(plain)), _const(4 << 20))
     assert got == O.compress(plain)
@@ -320,11 +331,12 @@ def test_garbage_decodes_like_the_reference_incremental_decoder():
             assert got == want and markers == v["markers"], v["in"]
 
 
-def test_large_pieces_decode_through_many_wavefronts():
+def test_large_pieces_decode_through_many_wavefronts(route):
     """Pieces of 16 KiB and more are decoded by many wavefronts as far as whole segments go
     (history, the bits left over from the call before and a running extension carried in), the
     rest by the one wavefront: several streams back to back (end markers in the middle of pieces),
     long runs, output space smaller and larger than what a piece produces."""
+    device_only(route)
     rng = random.Random(41)
     t = _sample("text", 900000)
     plains = [t[:400000], bytes(300000) + t[400000:500000] + b"q" * 200000, _sample("random", 150000), t[500000:900000]]
@@ -336,10 +348,11 @@ def test_large_pieces_decode_through_many_wavefronts():
         assert got == want and markers == len(plains), (ilo, ihi, olo, ohi, len(got), markers)
 
 
-def test_no_large_piece_is_left_to_one_wavefront():
+def test_no_large_piece_is_left_to_one_wavefront(route):
     """A copy still running when a call returns must not send the whole next piece to the one wavefront (round 4: half
     a MiB took 176 ms that way, one piece in fifty, against 0.7 ms for the others).  Sixty pieces of 256 KiB of one
     text stream, the slowest of them well under what one wavefront needs for such a piece (~90 ms)."""
+    device_only(route)
     import time
     plain = _sample("text", 24 << 20)
     stream = O.compress(plain)

@@ -1132,6 +1132,30 @@ def test_small_batch_in_device_memory_decompressed_in_segments():
             assert torch.equal(out[:, :cap], ref[:, :cap]) and torch.equal(out[:, :cap], x[:, :cap])
 
 
+def test_a_batch_whose_ring_does_not_fit_takes_the_serial_route_and_succeeds(monkeypatch):
+    """lzs_pipeline.c promises that a batch whose device ring (or pinned pieces) cannot be reserved takes the
+    one-after-the-other route instead of failing.  The failed hipMalloc stays the runtime's "last error" until it is
+    fetched, and every launcher returns the last error after its launch -- so the fallback's first launch used to be
+    in danger of reporting the stale out-of-memory as its own.  LZS_STAGING_FAIL_MB makes reservations
+    above a size fail by a real hipMalloc that cannot succeed: 800 blocks want a ring of 2 x 512 slots (75 MB), the
+    serial route 59 MB."""
+    x = workload.fill("text", 800)
+    cap = lzs.compressed_max(65536)
+    monkeypatch.setenv("LZS_STAGING_FAIL_MB", "70")
+    monkeypatch.setenv("LZS_STREAM_DEBUG", "1")               # (the pipeline reports itself on stderr when it runs)
+    out = np.zeros((800, cap), dtype=np.uint8)
+    out_len = np.zeros(800, dtype=np.uint32)
+    rc = lzs.lib().lzs_compress_batch(out.ctypes.data, cap, cap, out_len.ctypes.data, x.ctypes.data, 65536, None, 65536, 800)
+    assert rc == 0, lzs.last_error()
+    monkeypatch.delenv("LZS_STAGING_FAIL_MB")
+    monkeypatch.delenv("LZS_STREAM_DEBUG")
+    for blk in (0, 255, 256, 511, 799):
+        want = O.compress(bytes(x[blk]))
+        assert int(out_len[blk]) == len(want) and out[blk, :len(want)].tobytes() == want, blk
+    ref, ref_len = lzs.compress_batch(x)                      # (the overlapped route, unhindered)
+    assert np.array_equal(ref_len, out_len) and all(np.array_equal(ref[b, :ref_len[b]], out[b, :out_len[b]]) for b in range(0, 800, 37))
+
+
 def test_large_host_batches_take_the_overlapped_route_and_give_the_same_bytes(monkeypatch):
     """lzs_compress_batch / lzs_decompress_batch on HOST buffers from a few hundred MiB on: copy in, kernel and copy
     back run as a pipeline over chunks of blocks, host threads filling and emptying pinned pieces (lzs_pipeline.c).
