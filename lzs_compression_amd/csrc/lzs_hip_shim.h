@@ -60,6 +60,12 @@ int lzs_hip_load_check_state(int dev);
 int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                             const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                             uint32_t in_len, uint32_t nblocks, void *stream);
+/* lzs_hip_launch_compress() on a device that applies LDS exchanges in lane order launches one variant of the kernel per
+ * class of block over the same grid, and the blocks say which is theirs (lzs_classify_blocks_kernel leaves a code in
+ * d_out_len[b] until the block's length replaces it).  This runs the classifier alone: d_codes[b] = 0xFFFFFFF0 | 1 the default
+ * variant, | 2 few distinct grams (small tables, six workgroups per CU), | 3 nearly all literals (one full step per pass). */
+int lzs_hip_classify_blocks(uint32_t *d_codes, const void *d_in, size_t in_stride, const uint32_t *d_in_len, uint32_t in_len,
+                            uint32_t nblocks, void *stream);
 int lzs_hip_launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                               const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                               uint32_t in_len, uint32_t nblocks, void *stream);

@@ -13,8 +13,9 @@
  * tests run both routes against the same fixtures.
  *
  * Written from the rule of DESIGN.md section 2, and from the two device kernels whose contracts it shares
- * (lzs_compress_segments_kernel's piece of a stream, lzs_decode_resume_kernel's state block) -- not from oracle/, which
- * the product never touches (tests/test_abi.py).  What differs from both the reference and the oracle is the finder:
+ * (lzs_compress_segments_kernel's piece of a stream, lzs_decode_resume_kernel's state block) -- not from the checkers'
+ * restatement, which the product never touches (tests/test_abi.py).  What differs from both the reference and that
+ * restatement is the finder:
  * positions are chained by a hash of THREE bytes in a 2048-entry ring of distances (a match of 3 and more is on that
  * chain, nearest first), the nearest match of exactly two bytes is one look into a last-occurrence table of exact
  * 2-grams, and neither table is ever cleared: entries carry an epoch base, so what an earlier call left behind lies

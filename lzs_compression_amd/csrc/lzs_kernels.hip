@@ -44,7 +44,31 @@ namespace {
 #ifdef LZS_WITH_VARIANTS   // the earlier compressors ("chain", "scan") and the v1 decoder: A/B builds only
 #include "compress_variants.inc"                 // tools/variants/ (the Makefile adds the path for liblzs_variants.so only)
 #endif
+// The compress kernel, once per variant (kernels/compress_wg.inc says what the LZS_WGV_* mean): the default, the
+// order-independent CHAIN for a device that fails the LDS ordering check, and the two a block's class may ask for.
+namespace wgv_text {
+#define LZS_WGV_SEGMENTS 1
 #include "kernels/compress_wg.inc"
+}
+namespace wgv_safe {
+#define LZS_WGV_CHAIN_SAFE 1
+#define LZS_WGV_SEGMENTS 1
+#include "kernels/compress_wg.inc"
+}
+#ifndef LZS_ONE_VARIANT      // (tools/probes/ab.sh -DLZS_ONE_VARIANT: the default alone, for the probes that launch it directly)
+namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- a sixth workgroup per CU
+#define LZS_WGV_HEAD3 768
+#define LZS_WGV_HEAD2 512
+#include "kernels/compress_wg.inc"
+}
+namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop
+#define LZS_WGV_SUBSTEPS 1
+#include "kernels/compress_wg.inc"
+}
+#endif
+using wgv_text::lzs_compress_blocks_wg_kernel;        // (what tools/probes/ launch by name)
+using wgv_text::kWgThreads;
+#include "kernels/compress_aux.inc"
 #include "kernels/decompress_blocks.inc"
 #include "kernels/decompress_stream.inc"
 #include "kernels/compact_resume.inc"
@@ -239,8 +263,8 @@ static int verify_launch(void *d_out, size_t out_stride, uint32_t out_cap, uint3
     if (e == hipSuccess) e = hipMalloc((void **)&d_len2, sizeof(uint32_t) * ((size_t)nblocks + 1));
     if (e == hipSuccess) e = hipMemsetAsync(d_len2 + nblocks, 0, sizeof(uint32_t), stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0, stream, d_scratch, stride, out_cap, d_len2,
-                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 1u);
+        hipLaunchKernelGGL(wgv_safe::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0, stream, d_scratch, stride, out_cap, d_len2,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 0u);
         hipLaunchKernelGGL(lzs_verify_slots_kernel, dim3(nblocks), dim3(256), 0, stream, (const uint8_t *)d_out, (const uint32_t *)d_out_len,
                            (const uint8_t *)d_scratch, (const uint32_t *)d_len2, out_stride, stride, nblocks, d_len2 + nblocks);
         e = hipGetLastError();
@@ -284,9 +308,31 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0,
-                       (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, (uint32_t)chain_mode);
+    // Which variant compresses a block: the order-independent CHAIN for all of them on a device that needs it; otherwise the
+    // block's class decides, on the device (lzs_classify_blocks_kernel leaves a code in out_len[b]; every variant is launched
+    // over the whole grid and a workgroup whose block is another's returns at once: ~10 us per empty grid of 16 384).
+    // LZS_VARIANT=text|few|lit (development, read once) gives every block that one; small launches take the default alone.
+    static const int forced = [] {
+        const char *v = getenv("LZS_VARIANT");
+        return !v ? 0 : (v[0] == 't' ? 1 : (v[0] == 'f' ? 2 : (v[0] == 'l' ? 3 : 0)));
+    }();
+#define LZS_LAUNCH_VARIANT(ns, serve) \
+    hipLaunchKernelGGL(ns::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0, (hipStream_t)stream, (uint8_t *)d_out, out_stride, \
+                       out_cap, d_out_len, (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, serve)
+    if (chain_mode != 0) LZS_LAUNCH_VARIANT(wgv_safe, 0u);
+#ifndef LZS_ONE_VARIANT
+    else if (forced == 2) LZS_LAUNCH_VARIANT(wgv_few, 0u);
+    else if (forced == 3) LZS_LAUNCH_VARIANT(wgv_lit, 0u);
+    else if (forced == 0 && nblocks >= kClassifyMinBlocks) {
+        hipLaunchKernelGGL(lzs_classify_blocks_kernel, dim3((nblocks + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, d_out_len,
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+        LZS_LAUNCH_VARIANT(wgv_text, kClassCode | 1u);
+        LZS_LAUNCH_VARIANT(wgv_few, kClassCode | 2u);
+        LZS_LAUNCH_VARIANT(wgv_lit, kClassCode | 3u);
+    }
+#endif
+    else LZS_LAUNCH_VARIANT(wgv_text, 0u);
+#undef LZS_LAUNCH_VARIANT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (chain_mode == 0) {
@@ -297,6 +343,16 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
             return verify_launch(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, (hipStream_t)stream);
     }
     return 0;
+}
+
+// The classifier alone (tests, bench.py's class mix): d_codes[b] = 1 the default variant, 2 few distinct grams, 3 nearly all literals.
+int lzs_hip_classify_blocks(uint32_t *d_codes, const void *d_in, size_t in_stride, const uint32_t *d_in_len, uint32_t in_len,
+                            uint32_t nblocks, void *stream)
+{
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(lzs_classify_blocks_kernel, dim3((nblocks + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, d_codes,
+                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks);
+    return (int)hipGetLastError();
 }
 
 static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
@@ -358,10 +414,16 @@ int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const vo
     if (nseg == 0) return 0;
     int chain_mode = 0;
     { const int e = lzs_hip_chain_mode(stream, &chain_mode); if (e) return e; }
-    hipLaunchKernelGGL(lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
-                       (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
-                       d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
-                       (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open, (uint32_t)chain_mode);
+    if (chain_mode != 0)
+        hipLaunchKernelGGL(wgv_safe::lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
+                           (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
+                           d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
+                           (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open);
+    else
+        hipLaunchKernelGGL(wgv_text::lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
+                           (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
+                           d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
+                           (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open);
     return (int)hipGetLastError();
 }
 

@@ -27,6 +27,14 @@ def _need_gpu():
     assert "gfx950" in lzs.backend_info()
 
 
+@pytest.fixture(autouse=True)
+def _device_route(monkeypatch):
+    """Parity of the HIP path: every 4-argument call of this module is a launch, whatever its size (LZS_ROUTE=device).
+    The small calls' host route has the same fixtures to itself in tests/test_routes.py, and the route a caller gets
+    by default -- by size -- is compared with both there."""
+    monkeypatch.setenv("LZS_ROUTE", "device")
+
+
 def _rows(datas, stride=None):
     """Pack byte strings into a [n, stride] uint8 array + length vector."""
     stride = stride or max(1, max(len(d) for d in datas))
@@ -180,6 +188,68 @@ def test_class_digests_device_batch(class_digests, cls):
     offs = offsets.cpu().numpy()
     assert offs[0] == 0 and (np.diff(offs) == lens_h).all()
     assert hashlib.sha256(dense[:offs[-1]].cpu().numpy().tobytes()).hexdigest() == want["sha256"]
+
+
+def test_every_variant_of_the_compress_kernel_gives_the_reference_bytes_on_every_class():
+    """Round 5: a launch runs one variant of the compress kernel per class of block (small bucket tables and six
+    workgroups per CU for blocks of few distinct grams, one full step per pass of the SEARCH loop for blocks that are
+    nearly all literals, the default for the rest), and the blocks say which is theirs on the device.  The choice must
+    not show in the bytes: each variant forced on ALL three classes (LZS_VARIANT, read once per process: a process
+    each) gives the REAL reference's lengths and SHA-256 (tests/golden/class_digests.json), and so does the choice."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = (
+        "import hashlib, json, os, torch, lzs_compression_amd as lzs\n"
+        "from lzs_compression_amd import workload\n"
+        "d = json.load(open(os.path.join(%r, 'tests', 'golden', 'class_digests.json')))\n"
+        "for cls in workload.CLASS_NAMES:\n"
+        "    x = torch.from_numpy(workload.fill(cls, d['nblocks'], d['block_len'], seed=d['seed'])).cuda()\n"
+        "    slots, n = lzs.compress_blocks(x)\n"
+        "    torch.cuda.synchronize()\n"
+        "    out, n = slots.cpu().numpy(), n.cpu().numpy()\n"
+        "    assert n.tolist() == d['classes'][cls]['len'], cls\n"
+        "    h = hashlib.sha256()\n"
+        "    for b in range(len(n)): h.update(out[b, :n[b]].tobytes())\n"
+        "    assert h.hexdigest() == d['classes'][cls]['sha256'], cls\n"
+        "print('ok')\n" % root)
+    for variant in ("", "text", "few", "lit"):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("LZS_VARIANT", None)
+        if variant:
+            env["LZS_VARIANT"] = variant
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout.split(), (variant, r.stderr[-2000:])
+
+
+def test_the_blocks_of_the_three_classes_get_their_variants_and_mixed_batches_stay_exact():
+    """lzs_classify_blocks_kernel: the distinct 2-grams among a block's first 2048 positions (a 4096-bit hashed set) --
+    text ~430, the low-entropy class <= 53, random bytes ~1610 -- choose the variant; blocks shorter than that take the
+    default.  A batch of all three classes interleaved, ragged, is compressed by three launches over one grid and every
+    block equals the oracle's."""
+    import ctypes
+    L = lzs.lib()
+    L.lzs_hip_classify_blocks.restype = ctypes.c_int
+    L.lzs_hip_classify_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    nb = 96
+    parts = [workload.fill(c, nb) for c in workload.CLASS_NAMES]
+    mixed = np.stack([parts[b % 3][b // 3] for b in range(3 * nb)])
+    x = torch.from_numpy(mixed).cuda()
+    codes = torch.zeros(3 * nb, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert L.lzs_hip_classify_blocks(codes.data_ptr(), x.data_ptr(), 65536, None, 65536, 3 * nb, None) == 0
+    torch.cuda.synchronize()
+    got = (codes.cpu().numpy().astype(np.int64) & 0xF).tolist()
+    assert got == [1, 2, 3] * nb, got[:12]
+    lens = np.full(3 * nb, 65536, dtype=np.uint32)
+    lens[5::7] = np.random.default_rng(3).integers(0, 65536, len(lens[5::7]))
+    lens[0], lens[1], lens[2] = 2048, 2049, 0
+    slots, n = lzs.compress_blocks(x, torch.from_numpy(lens.astype(np.int32)).cuda())
+    torch.cuda.synchronize()
+    out, n = slots.cpu().numpy(), n.cpu().numpy()
+    for b in range(3 * nb):
+        want = O.compress(mixed[b, :lens[b]].tobytes())
+        assert int(n[b]) == len(want) and out[b, :n[b]].tobytes() == want, (b, lens[b])
 
 
 # ------------------------------------------------------------ differential vs the oracle

@@ -21,7 +21,7 @@ int main(int argc, char **argv)
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a);
         hipLaunchKernelGGL(lzs_compress_blocks_wg_kernel, dim3(nb), dim3(256), 0, 0, d_out, stride, 73731u, d_len,
-                           (const uint8_t *)d_in, (size_t)bl, (const uint32_t *)nullptr, bl, nb, getenv("LZS_CHAIN_FALLBACK") ? 1u : 0u);
+                           (const uint8_t *)d_in, (size_t)bl, (const uint32_t *)nullptr, bl, nb, 0u);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         static unsigned long long P[4][kProfN];
