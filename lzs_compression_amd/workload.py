@@ -16,7 +16,8 @@ DEFAULT_SEED = 0x4C5A5331          # "LZS1"
 CLASS_NAMES = ("text", "lowent", "random")
 TEXT, LOWENT, RANDOM = 0, 1, 2
 
-_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblzs_workload.so")
+# (LZS_WORKLOAD_SO: another build of the generator -- the sanitizer run of the checkers builds one with ASan / UBSan)
+_SO = os.environ.get("LZS_WORKLOAD_SO") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblzs_workload.so")
 _SO_HIP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblzs_workload_hip.so")
 _lib = None
 _lib_hip = None

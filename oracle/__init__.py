@@ -22,7 +22,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_ORACLE_SO = os.path.join(_HERE, "liblzs_oracle.so")
+# (LZS_ORACLE_SO: another build of the restatement -- tests/test_sanitizers.py points it at oracle/_build/liblzs_oracle_asan.so)
+_ORACLE_SO = os.environ.get("LZS_ORACLE_SO") or os.path.join(_HERE, "liblzs_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "liblzs_ref.so")
 
 _SIG = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]

@@ -258,6 +258,17 @@ static void incremental(void)
     free(t); free(low); free(mix);
 }
 
+/* proof that the harness is alive: "device" memory is instrumented heap memory (the test expects the sanitizer to stop this) */
+int lzs_hip_malloc(void **p, size_t bytes);
+static void canary(void)
+{
+    void *d = NULL;
+    lzs_hip_malloc(&d, 100);
+    volatile uint8_t *q = (volatile uint8_t *)d;
+    q[100] = 1;                                  /* one byte past a device buffer */
+    printf("canary: the write past the buffer went unnoticed\n");
+}
+
 int main(int argc, char **argv)
 {
     setenv("LZS_DEV_ENV", "1", 1);          /* the switches are read afresh on every call: this program flips them */
@@ -269,6 +280,7 @@ int main(int argc, char **argv)
     if (!*only || !strcmp(only, "streams")) one_shot_streams();
     if (!*only || !strcmp(only, "incremental")) incremental();
     if (!*only || !strcmp(only, "pipeline")) pipeline();
+    if (!strcmp(only, "canary")) canary();
     printf("san_driver: %d failure(s)\n", failures);
     return failures ? 1 : 0;
 }
