@@ -79,13 +79,14 @@ def usable_cores() -> int:
 
 def kernel_identity() -> str:
     """SHA-256 over the sources the measured kernel, lzs_compress_blocks_wg_kernel, is compiled from
-    (kernels/common.inc and kernels/compress_wg.inc: its code, its LDS layout and its launch
-    geometry -- one workgroup of kWgThreads per block): what a counter measurement belongs to.
+    (kernels/common.inc, kernels/compress_wg.inc and kernels/compress_aux.inc: its code in every variant, its LDS
+    layout, its launch geometry -- one workgroup of kWgThreads per block -- and the classifier that gives a block its
+    variant): what a counter measurement belongs to.
     (The decoders' sources are not part of it: the traffic figure is the compress kernel's.)"""
     import hashlib
     csrc = os.path.join(ROOT, "lzs_compression_amd", "csrc", "kernels")
     h = hashlib.sha256()
-    for name in ("common.inc", "compress_wg.inc"):
+    for name in ("common.inc", "compress_wg.inc", "compress_aux.inc"):
         h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()
 
@@ -930,6 +931,9 @@ def single(args) -> int:
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic if traffic else traffic_note,
                      "kernel": "lzs_compress_blocks_wg_kernel",
+                     "kernel_note": "one launch = lzs_classify_blocks_kernel + the kernel's variant for each class of block over the same "
+                                    "grid (wgv_text the default, wgv_few small tables / six workgroups per CU, wgv_lit one full step per pass; "
+                                    "a workgroup whose block is another variant's returns at once): the events bracket all of them",
                      "algorithmic_bytes_per_launch": {"read_input": in_bytes,
                                                       "total_read_plus_written": algo_bytes},
                      "avg_kernel_ms": avg_ms, "min_kernel_ms": float(np.min(kernel_ms)),
@@ -994,6 +998,18 @@ def single(args) -> int:
                     result["other_classes"][cls] = other_class(cls, nb, dev)
                 except Exception as exc:                  # noqa: BLE001 -- an extra, never the contract line's problem
                     result["other_classes"][cls] = {"error": f"{type(exc).__name__}: {exc}"}
+    # All three classes where the driver parses them: BASELINE.json configs[1..3] as first-class numbers
+    # inside `roofline`, each measured like the headline and checked block by block.
+    by_class = {args.workload: {"GBps": achieved, "frac": achieved / HBM_PEAK_GBS, "kernel_ms": avg_ms, "ratio": ratio,
+                                "checked_blocks": ((result.get("cpu_baseline") or {}).get("check") or {}).get("blocks_compared"),
+                                "bit_exact": ((result.get("cpu_baseline") or {}).get("check") or {}).get("bit_exact")}}
+    for cls, r in (result.get("other_classes") or {}).items():
+        if "error" in r:
+            by_class[cls] = {"error": r["error"]}
+        else:
+            by_class[cls] = {"GBps": r["roofline"]["achieved"], "frac": r["roofline"]["frac"], "kernel_ms": r["avg_kernel_ms"],
+                             "ratio": r["compression_ratio"], "checked_blocks": r["check"]["blocks_compared"], "bit_exact": r["check"]["bit_exact"]}
+    result["roofline"]["by_class"] = by_class
     if not args.no_config5:
         try:
             result["config5_world1"] = config5_world1(args, dev)

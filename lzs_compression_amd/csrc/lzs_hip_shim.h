@@ -44,6 +44,7 @@ void lzs_hip_clear_error(void);
 int lzs_hip_words_to_host(uint32_t *h_dst, const uint32_t *d_src, size_t nwords, void *stream);
 int lzs_hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int lzs_hip_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int lzs_hip_memset(void *dst, int value, size_t bytes, void *stream);
 
 /* How CHAIN links the positions of a batch on the current device: 0 = by one ordered LDS exchange

@@ -147,6 +147,10 @@ int lzs_hip_d2h(void *d, const void *s, size_t n, void *st)
 {
     return n ? (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st) : 0;
 }
+int lzs_hip_d2d(void *d, const void *s, size_t n, void *st)
+{
+    return n ? (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st) : 0;
+}
 int lzs_hip_memset(void *d, int v, size_t n, void *st)
 {
     return n ? (int)hipMemsetAsync(d, v, n, (hipStream_t)st) : 0;

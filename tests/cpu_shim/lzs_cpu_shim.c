@@ -66,6 +66,7 @@ int lzs_hip_event_done(void *e) { (void)e; return 1; }
 int lzs_hip_stream_wait_event(void *s, void *e) { (void)s; (void)e; return 0; }
 int lzs_hip_h2d(void *d, const void *s, size_t n, void *st) { (void)st; if (n) memcpy(d, s, n); return 0; }
 int lzs_hip_d2h(void *d, const void *s, size_t n, void *st) { (void)st; if (n) memcpy(d, s, n); return 0; }
+int lzs_hip_d2d(void *d, const void *s, size_t n, void *st) { (void)st; if (n) memmove(d, s, n); return 0; }
 int lzs_hip_memset(void *d, int v, size_t n, void *st) { (void)st; if (n) memset(d, v, n); return 0; }
 int lzs_hip_words_to_host(uint32_t *h, const uint32_t *d, size_t nwords, void *st) { (void)st; if (nwords) memcpy(h, d, 4 * nwords); return launched(); }
 int lzs_hip_chain_mode(void *stream, int *mode) { (void)stream; *mode = 0; return 0; }

@@ -145,3 +145,51 @@ print("ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "ok" in r.stdout.split(), r.stderr[-2000:]      # (RCCL prints its version banner after it)
+
+
+def test_the_c_entries_of_the_sharded_job_at_world_one():
+    """include/lzs/lzs_shard.h from a C host's point of view (ctypes here): lzs_shard_range, lzs_rccl_scatter_blocks,
+    the batch call, lzs_compact_device, lzs_rccl_gather_streams -- at world size 1 on the one GPU of the test box, with a
+    real one-rank communicator (ncclCommInitAll), so that the library's run-time binding of librccl and its
+    ncclAllGather of the byte counts are exercised on hardware.  The gathered bytes are the oracle's streams back to back."""
+    import ctypes
+    import oracle
+    import lzs_compression_amd as lzs
+    from lzs_compression_amd import workload
+    L = lzs.lib()
+    vp, sz, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)
+    L.lzs_rccl_scatter_blocks.restype = ctypes.c_int
+    L.lzs_rccl_scatter_blocks.argtypes = [vp, vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.lzs_rccl_gather_streams.restype = ctypes.c_int
+    L.lzs_rccl_gather_streams.argtypes = [vp, vp, u64p, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "librccl is not on this box"
+    comm = ctypes.c_void_p()
+    dev0 = (ctypes.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, dev0) == 0
+    try:
+        nb = 96
+        host = workload.fill("text", nb, 65536)
+        everything = torch.from_numpy(host).cuda()
+        mine = torch.empty_like(everything)
+        stream = torch.cuda.current_stream().cuda_stream
+        assert L.lzs_rccl_scatter_blocks(comm, mine.data_ptr(), everything.data_ptr(), nb, 65536, 0, 1, 0, stream) == 0, lzs.last_error()
+        slots, lens = lzs.compress_blocks(mine)
+        dense, offs = lzs.compact(slots, lens)
+        d_counts = torch.zeros(1, dtype=torch.int64, device="cuda")
+        counts = (ctypes.c_uint64 * 1)()
+        out = torch.zeros(int(dense.numel()), dtype=torch.uint8, device="cuda")
+        rc = L.lzs_rccl_gather_streams(comm, out.data_ptr(), counts, d_counts.data_ptr(), dense.data_ptr(),
+                                       offs.data_ptr() + 8 * nb, 0, 1, 0, stream)
+        assert rc == 0, lzs.last_error()
+        torch.cuda.synchronize()
+        want = b"".join(oracle.oracle().compress(host[b].tobytes()) for b in range(nb))
+        assert counts[0] == len(want) and out[:counts[0]].cpu().numpy().tobytes() == want
+    finally:
+        rccl.ncclCommDestroy(comm)

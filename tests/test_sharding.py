@@ -175,3 +175,23 @@ def test_shard_ranges_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_the_c_entry_partitions_like_the_python_job():
+    """lzs_shard_range() (include/lzs/lzs_shard.h, csrc/lzs_rccl.c: what a C host of the sharded job calls) gives the
+    ranges sharding.shard_range gives; liblzs.so opens librccl only when a transfer call runs, never at load time."""
+    import ctypes
+    import subprocess
+    import lzs_compression_amd as lzs
+    L = lzs.lib()
+    L.lzs_shard_range.restype = None
+    L.lzs_shard_range.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    for n in (0, 1, 7, 100, 16384, 1048576, 1048577):
+        for world in (1, 2, 3, 5, 8):
+            for r in range(world):
+                lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+                L.lzs_shard_range(n, r, world, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == sharding.shard_range(n, r, world), (n, r, world)
+    so = os.path.join(os.path.dirname(os.path.abspath(lzs.__file__)), "liblzs.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed
