@@ -29,6 +29,11 @@ const char *lzs_last_error(void) { return tls_error; }
 
 LZS_HIDDEN int require_device(void)
 {
+    /* (asked once per process: a device that was there and answered the ordering check does not go away, and a call on
+     * the small calls' host route -- 5 us of work at the reference tools' 512-byte reads -- should not pay two runtime
+     * calls to hear it again; a device that fails later fails the HIP call that meets it) */
+    static int device_ok;
+    if (__atomic_load_n(&device_ok, __ATOMIC_ACQUIRE)) return LZS_OK;
     int n = 0;
     int e = lzs_hip_device_count(&n);
     if (e != 0 || n <= 0)
@@ -39,6 +44,7 @@ LZS_HIDDEN int require_device(void)
      * allocates nor waits */
     int mode = 0;
     if ((e = lzs_hip_chain_mode(NULL, &mode)) != 0) return hip_fail(e, "LDS ordering check");
+    __atomic_store_n(&device_ok, 1, __ATOMIC_RELEASE);
     return LZS_OK;
 }
 

@@ -248,9 +248,10 @@ LZS_HIDDEN size_t hostcodec_compress_piece(uint8_t *out, size_t cap, const uint8
 }
 
 /* ---------------------------------------------------------------- decoding
- * One engine for the one-shot call and for the resumable one: bits come MSB first from a 64-bit buffer fed a byte at a
- * time, every field is believed only once all its bits are there (lzs-decompression.c:220-223, 238-251, 272-275,
- * 325-335), a copy replicates byte by byte (:346-365) and reads zero before the first byte there is (:350-357). */
+ * One engine for the one-shot call and for the resumable one: bits come MSB first from a 64-bit buffer topped up eight
+ * bytes at a time, every field is believed only once all its bits are there (lzs-decompression.c:220-223, 238-251,
+ * 272-275, 325-335), a copy replicates byte by byte (:346-365) and reads zero before the first byte there is
+ * (:350-357) -- or, in a resumed stream, what the history holds there. */
 typedef struct {
     const uint8_t *in; size_t n, ipos;
     uint64_t bits; unsigned have;                               /* left-aligned */
@@ -258,10 +259,102 @@ typedef struct {
 
 static inline void hc_feed(hc_reader_t *r)
 {
+    if (r->n - r->ipos >= 8u) {                                 /* eight bytes at once, as many of them as fit taken */
+        uint64_t w;
+        memcpy(&w, r->in + r->ipos, 8);
+        w = __builtin_bswap64(w);
+        const unsigned take = (64u - r->have) >> 3;             /* whole bytes of room: 1 .. 8 (have <= 56) */
+        r->bits |= r->have ? (w >> r->have) & (~0ull << (64u - r->have - 8u * take)) : w;
+        r->ipos += take;
+        r->have += 8u * take;
+        return;
+    }
     while (r->have <= 56u && r->ipos < r->n) {
         r->bits |= (uint64_t)r->in[r->ipos++] << (56u - r->have);
         r->have += 8u;
     }
+}
+
+/* what stops a decoder (the LZS_INC_* bits of lzs_hip_shim.h, which are the reference's status bits) */
+typedef struct {
+    uint32_t off, rem; int extended;        /* the copy in progress: offset, bytes left, a length nibble follows */
+    const uint8_t *hist; uint32_t hist_len; /* bytes in front of out[0] a copy may reach into (resumed streams) */
+} hc_copy_t;
+
+/* Decodes until the input gives no whole field any more, the output is full, or (one_shot) the first end marker / (else)
+ * any end marker.  Returns the status bits; *count bytes are in out. */
+static inline uint32_t hc_decode(hc_reader_t *r, hc_copy_t *c, uint8_t *out, size_t cap, size_t *count_out, int one_shot)
+{
+    size_t count = 0;
+    uint32_t off = c->off, rem = c->rem, status = 0;
+    int extended = c->extended;
+    for (;;) {
+        if (r->have < 32u) hc_feed(r);
+        /* no bit left: the incremental decoder stops here whatever it was doing, also with a copy pending (:475-478,
+         * :492-496); the one-shot decoder has done its copy by the time it looks (:189 comes after :346-365) */
+        if (r->have == 0 && !(one_shot && rem)) { status |= LZS_INC_INPUT_FINISHED | LZS_INC_INPUT_STARVED; break; }
+        if (rem) {                                              /* the copy (:346-365, :381-400; :640-704) */
+            const size_t room = cap - count;
+            if (room == 0) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
+            uint32_t m = rem < room ? rem : (uint32_t)room;
+            rem -= m;
+            if (count >= off && off >= m && m >= 4u) {          /* no overlap: two moves that meet (nothing past the m bytes is touched) */
+                uint8_t *d = out + count;
+                const uint8_t *q = d - off;
+                if (m >= 8u) { uint64_t a, z; memcpy(&a, q, 8); memcpy(&z, q + m - 8u, 8); memcpy(d, &a, 8); memcpy(d + m - 8u, &z, 8); }
+                else         { uint32_t a, z; memcpy(&a, q, 4); memcpy(&z, q + m - 4u, 4); memcpy(d, &a, 4); memcpy(d + m - 4u, &z, 4); }
+                count += m;
+            } else if (count >= off) {
+                for (; m; m--, count++) out[count] = out[count - off];
+            } else {
+                for (; m; m--, count++) {
+                    const size_t back = off - count;            /* before out[0]: the history, or zero (:350-357, :676-683) */
+                    out[count] = count >= off ? out[count - off] : (back <= c->hist_len ? c->hist[c->hist_len - back] : 0);
+                }
+            }
+            continue;
+        }
+        if (one_shot && count >= cap) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }      /* :200 */
+        if (extended) {                                         /* :370-406, :706-723 */
+            if (r->have < 4u) { status |= LZS_INC_INPUT_STARVED; break; }
+            const unsigned e = (unsigned)(r->bits >> 60);
+            r->bits <<= 4; r->have -= 4u;
+            rem = e;
+            if (e != HC_NIBBLE) extended = 0;
+        } else if ((r->bits >> 63) == 0) {                      /* literal :217-233, :516-541 */
+            if (r->have < 9u) { status |= LZS_INC_INPUT_STARVED; break; }
+            if (count >= cap) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
+            out[count++] = (uint8_t)(r->bits >> 55);
+            r->bits <<= 9; r->have -= 9u;
+        } else {
+            const int is_short = (int)((r->bits >> 62) & 1u);
+            const unsigned used = is_short ? 9u : 13u;
+            if (r->have < used) { status |= LZS_INC_INPUT_STARVED; break; }             /* :238-251, :272-275 */
+            const unsigned o = is_short ? (unsigned)(r->bits >> 55) & 0x7Fu : (unsigned)(r->bits >> 51) & 0x7FFu;
+            if (o == 0) {
+                if (is_short && one_shot) { status |= LZS_INC_END_MARKER; break; }      /* :255-260: nothing after it is looked at */
+                r->bits <<= used; r->have -= used;
+                if (is_short) {                                 /* end marker: the pad bits go, history stays (:564-576) */
+                    const unsigned pad = r->have & 7u;
+                    r->bits <<= pad; r->have -= pad;
+                    status |= LZS_INC_END_MARKER;
+                    break;
+                }
+                off = 0;                                        /* long offset 0: no copy, not an end marker (:280) */
+            } else {
+                const unsigned code = (unsigned)((r->bits << used) >> 60);
+                const unsigned width = code < 0xCu ? 2u : 4u;   /* :103-120, :325-342 */
+                if (r->have < used + width) { status |= LZS_INC_INPUT_STARVED; break; }   /* the token's bits stay queued */
+                const unsigned len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
+                r->bits <<= used + width; r->have -= used + width;
+                off = o; rem = len;
+                extended = len == HC_TOKEN;
+            }
+        }
+    }
+    c->off = off; c->rem = rem; c->extended = extended;
+    *count_out = count;
+    return status;
 }
 
 /* lzs_decompress() (lzs-decompression.c:156-412): stops at the first end marker, when the output is full (also in the
@@ -269,120 +362,24 @@ static inline void hc_feed(hc_reader_t *r)
 LZS_HIDDEN size_t hostcodec_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n)
 {
     hc_reader_t r = { in, n, 0, 0, 0 };
+    hc_copy_t c = { 0, 0, 0, NULL, 0 };
     size_t count = 0;
-    unsigned off = 0;
-    int extended = 0;
-    for (;;) {
-        hc_feed(&r);
-        if (r.have == 0 || count >= cap) break;                 /* :189, :200 */
-        unsigned len;
-        if (extended) {                                         /* :370-406 */
-            if (r.have < 4u) break;
-            len = (unsigned)(r.bits >> 60);
-            r.bits <<= 4; r.have -= 4u;
-            if (len != HC_NIBBLE) extended = 0;
-        } else if ((r.bits >> 63) == 0) {                       /* literal :217-233 */
-            if (r.have < 9u) break;
-            out[count++] = (uint8_t)(r.bits >> 55);
-            r.bits <<= 9; r.have -= 9u;
-            continue;
-        } else {
-            if (r.have < 2u) break;                             /* :238-241 */
-            const int is_short = (int)((r.bits >> 62) & 1u);
-            const unsigned used = is_short ? 9u : 13u;
-            if (r.have < used) break;                           /* :248-251, :272-275 */
-            const unsigned o = is_short ? (unsigned)(r.bits >> 55) & 0x7Fu : (unsigned)(r.bits >> 51) & 0x7FFu;
-            if (o == 0) {
-                if (is_short) break;                            /* end marker :255-260 */
-                r.bits <<= used; r.have -= used;                /* long offset 0: no copy, not an end marker (:280) */
-                continue;
-            }
-            const unsigned code = (unsigned)((r.bits << used) >> 60);
-            const unsigned width = code < 0xCu ? 2u : 4u;       /* :103-120, :325-342 */
-            if (r.have < used + width) {
-                /* (the reference has consumed the offset by now and stops on the length: nothing is produced either way) */
-                break;
-            }
-            len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
-            r.bits <<= used + width; r.have -= used + width;
-            off = o;
-            extended = len == HC_TOKEN;
-        }
-        /* the copy: byte by byte, zero before out[0], cut where the output is full (:346-365, :381-400) */
-        size_t m = len;
-        int full = 0;
-        if (m >= cap - count) { m = cap - count; full = len >= cap - count; }
-        if (count >= off && off >= m) { memcpy(out + count, out + count - off, m); count += m; }
-        else for (size_t i = 0; i < m; i++, count++) out[count] = count >= off ? out[count - off] : 0;
-        if (full) break;
-    }
+    (void)hc_decode(&r, &c, out, cap, &count, 1);
     return count;
 }
 
 /* lzs_decompress_incremental()'s engine on the host: the contract of lzs_decode_resume_kernel (kernels/compact_resume.inc;
- * reference lzs-decompression.c:459-743), same state block, same stop rules at token granularity. */
-LZS_HIDDEN void hostcodec_decode_resume(lzs_dec_resume_t *st, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap)
+ * reference lzs-decompression.c:459-743), same state, same stop rules at token granularity.  The state is handed over by
+ * its fields (the incremental call keeps it in the caller's block and passes that: no copies of the history). */
+LZS_HIDDEN void hostcodec_decode_resume_fields(uint32_t *bitq, uint32_t *qlen, uint32_t *off, uint32_t *rem, uint32_t *extended,
+                                               uint8_t *hist, uint32_t *hist_len, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
+                                               uint32_t *in_used, uint32_t *out_made, uint32_t *status_out)
 {
-    hc_reader_t r = { in, n, 0, (uint64_t)st->bitq << 32, st->qlen };
-    const unsigned carried = st->qlen;
-    const uint8_t *hist = st->hist;
-    const uint32_t hist_len = st->hist_len;
-    uint32_t off = st->off, rem = st->rem, count = 0, status = 0;
-    int extended = st->extended != 0;
-    for (;;) {
-        hc_feed(&r);
-        /* no bit left: the reference stops here whatever it was doing, also with a copy pending (:475-478, :492-496) */
-        if (r.have == 0) { status |= LZS_INC_INPUT_FINISHED | LZS_INC_INPUT_STARVED; break; }
-        if (rem) {                                              /* :640-704 */
-            const uint32_t room = cap - count;
-            if (room == 0) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
-            uint32_t m = rem < room ? rem : room;
-            rem -= m;
-            if (count >= off && off >= m) { memcpy(out + count, out + count - off, m); count += m; }
-            else for (; m; m--, count++) {
-                uint8_t v;
-                if (count >= off) v = out[count - off];
-                else { const uint32_t back = off - count; v = back <= hist_len ? hist[hist_len - back] : 0; }   /* (:676-683) */
-                out[count] = v;
-            }
-            continue;
-        }
-        if (extended) {                                         /* :706-723 */
-            if (r.have < 4u) { status |= LZS_INC_INPUT_STARVED; break; }
-            const unsigned e = (unsigned)(r.bits >> 60);
-            r.bits <<= 4; r.have -= 4u;
-            rem = e;
-            if (e != HC_NIBBLE) extended = 0;
-        } else if ((r.bits >> 63) == 0) {                       /* literal :516-541 */
-            if (r.have < 9u) { status |= LZS_INC_INPUT_STARVED; break; }
-            if (count >= cap) { status |= LZS_INC_NO_OUTPUT_SPACE; break; }
-            out[count++] = (uint8_t)(r.bits >> 55);
-            r.bits <<= 9; r.have -= 9u;
-        } else {
-            const int is_short = (int)((r.bits >> 62) & 1u);
-            const unsigned used = is_short ? 9u : 13u;
-            if (r.have < used) { status |= LZS_INC_INPUT_STARVED; break; }
-            const unsigned o = is_short ? (unsigned)(r.bits >> 55) & 0x7Fu : (unsigned)(r.bits >> 51) & 0x7FFu;
-            if (o == 0) {
-                r.bits <<= used; r.have -= used;
-                if (is_short) {                                 /* end marker: the pad bits go, history stays (:564-576) */
-                    const unsigned pad = r.have & 7u;
-                    r.bits <<= pad; r.have -= pad;
-                    status |= LZS_INC_END_MARKER;
-                    break;
-                }
-                off = 0;                                        /* long offset 0: no copy */
-            } else {
-                const unsigned code = (unsigned)((r.bits << used) >> 60);
-                const unsigned width = code < 0xCu ? 2u : 4u;
-                if (r.have < used + width) { status |= LZS_INC_INPUT_STARVED; break; }      /* the token's bits stay queued */
-                const unsigned len = code < 0xCu ? 2u + (code >> 2) : code - 7u;
-                r.bits <<= used + width; r.have -= used + width;
-                off = o; rem = len;
-                extended = len == HC_TOKEN;
-            }
-        }
-    }
+    hc_reader_t r = { in, n, 0, (uint64_t)*bitq << 32, *qlen };
+    const unsigned carried = *qlen;
+    hc_copy_t c = { *off, *rem, *extended != 0, hist, *hist_len };
+    size_t count = 0;
+    const uint32_t status = hc_decode(&r, &c, out, cap, &count, 0);
     /* whole bytes of this call's input that were not needed go back to the caller; a starved call keeps the unfinished
      * token's bits (< 17) and takes all the input, as the reference does */
     const uint32_t fed = (uint32_t)r.ipos;
@@ -392,18 +389,24 @@ LZS_HIDDEN void hostcodec_decode_resume(lzs_dec_resume_t *st, const uint8_t *in,
     r.have -= 8u * back;
     /* the history: the last 2047 bytes of what was there and what came now */
     if (count >= HC_WINDOW) {
-        memcpy(st->hist, out + count - HC_WINDOW, HC_WINDOW);
-        st->hist_len = HC_WINDOW;
+        memcpy(hist, out + count - HC_WINDOW, HC_WINDOW);
+        *hist_len = HC_WINDOW;
     } else if (count) {
-        const uint32_t keep = hist_len + count > HC_WINDOW ? HC_WINDOW - count : hist_len;
-        memmove(st->hist, st->hist + hist_len - keep, keep);
-        memcpy(st->hist + keep, out, count);
-        st->hist_len = keep + count;
+        const uint32_t keep = *hist_len + (uint32_t)count > HC_WINDOW ? HC_WINDOW - (uint32_t)count : *hist_len;
+        memmove(hist, hist + *hist_len - keep, keep);
+        memcpy(hist + keep, out, count);
+        *hist_len = keep + (uint32_t)count;
     }
-    st->bitq = r.have ? (uint32_t)(r.bits >> 32) & (~0u << (32u - (r.have > 32u ? 32u : r.have))) : 0u;
-    st->qlen = r.have;
-    st->off = off; st->rem = rem; st->extended = extended ? 1u : 0u;
-    st->in_used = fed - back;
-    st->out_made = count;
-    st->status = status;
+    *bitq = r.have ? (uint32_t)(r.bits >> 32) & (~0u << (32u - r.have)) : 0u;      /* (at most 16 bits stay: see above) */
+    *qlen = r.have;
+    *off = c.off; *rem = c.rem; *extended = c.extended ? 1u : 0u;
+    *in_used = fed - back;
+    *out_made = (uint32_t)count;
+    *status_out = status;
+}
+
+LZS_HIDDEN void hostcodec_decode_resume(lzs_dec_resume_t *st, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap)
+{
+    hostcodec_decode_resume_fields(&st->bitq, &st->qlen, &st->off, &st->rem, &st->extended, st->hist, &st->hist_len, in, n, out, cap,
+                                   &st->in_used, &st->out_made, &st->status);
 }

@@ -47,25 +47,23 @@ void lzs_decompress_init(LzsDecompressParameters_t *p)
 static size_t dec_incremental_host(LzsDecompressParameters_t *p, dec_priv_t *pv)
 {
     size_t made = 0;
-    lzs_dec_resume_t h;
     for (;;) {
         const size_t take = p->inLength < ((size_t)1 << 30) ? p->inLength : ((size_t)1 << 30);
         const size_t cap = p->outLength < 0xF0000000u ? p->outLength : 0xF0000000u;
-        h.bitq = pv->bitq; h.qlen = pv->qlen; h.off = pv->off; h.rem = pv->rem;
-        h.extended = pv->extended; h.hist_len = pv->hist_len;
-        h.in_used = h.out_made = h.status = h.reserved = 0;
-        memcpy(h.hist, pv->hist, pv->hist_len);
-        hostcodec_decode_resume(&h, p->inPtr, (uint32_t)take, p->outPtr, (uint32_t)cap);
-        pv->bitq = h.bitq; pv->qlen = (uint8_t)h.qlen; pv->off = (uint16_t)h.off; pv->rem = (uint8_t)h.rem;
-        pv->extended = (uint8_t)h.extended; pv->hist_len = (uint16_t)h.hist_len;
-        memcpy(pv->hist, h.hist, h.hist_len);
-        p->inPtr += h.in_used;   p->inLength -= h.in_used;
-        p->outPtr += h.out_made; p->outLength -= h.out_made;
-        made += h.out_made;
+        /* (the state lives in the caller's block, packed: its fields by value, the history in place) */
+        uint32_t bitq = pv->bitq, qlen = pv->qlen, off = pv->off, rem = pv->rem, extended = pv->extended, hist_len = pv->hist_len;
+        uint32_t in_used = 0, out_made = 0, status = 0;
+        hostcodec_decode_resume_fields(&bitq, &qlen, &off, &rem, &extended, pv->hist, &hist_len, p->inPtr, (uint32_t)take, p->outPtr, (uint32_t)cap,
+                                       &in_used, &out_made, &status);
+        pv->bitq = bitq; pv->qlen = (uint8_t)qlen; pv->off = (uint16_t)off; pv->rem = (uint8_t)rem;
+        pv->extended = (uint8_t)extended; pv->hist_len = (uint16_t)hist_len;
+        p->inPtr += in_used;   p->inLength -= in_used;
+        p->outPtr += out_made; p->outLength -= out_made;
+        made += out_made;
         /* stopped only because of this loop's own limits: go on */
-        if ((h.status & LZS_INC_INPUT_STARVED) && p->inLength) continue;
-        if ((h.status & LZS_INC_NO_OUTPUT_SPACE) && p->outLength) continue;
-        p->status = (uint8_t)h.status;
+        if ((status & LZS_INC_INPUT_STARVED) && p->inLength) continue;
+        if ((status & LZS_INC_NO_OUTPUT_SPACE) && p->outLength) continue;
+        p->status = (uint8_t)status;
         return made;
     }
 }

@@ -88,12 +88,17 @@ LZS_HIDDEN int host_batch_pipelined(const char *who, launch_fn launch, uint8_t *
 #define LZS_ROUTE_AUTO 0
 #define LZS_ROUTE_DEVICE 1
 #define LZS_ROUTE_HOST 2
-/* the crossovers, measured on the GPU box (profiles/r05/route_crossover.txt): below them one host core is faster than a
- * launch and its wait */
+/* the crossovers, measured on the GPU box (profiles/r05/route_crossover.txt, text; one core of an EPYC 9575F against the
+ * MI355X): below them one host core is faster than a launch and its wait.  us a call, device / host:
+ *   lzs_compress()    4 KiB 99 / 12.5, 16 KiB 118 / 48, 32 KiB 125 / 242          -> 16 KiB of input
+ *   lzs_decompress()  16 KiB of output 346 / 14, 64 KiB 494 / 163, 128 KiB 502 / 361, 256 KiB 517 / 736
+ *                                                                                   -> 64 KiB of compressed bytes (~115 KiB of text)
+ *   lzs_decompress_incremental(), MB/s: 512-byte calls 4.5 / 204, 64 KiB 223 / 339, 256 KiB 773 / 334   -> 64 KiB a call
+ *   lzs_compress_incremental(), MB/s: 512-byte calls 65 / 94, 4 KiB 87 / 109, 16 KiB 119 / 112            -> 16 KiB to decide */
 #define HOST_COMPRESS_MAX    16384u     /* lzs_compress(): input bytes */
 #define HOST_DECOMPRESS_MAX  65536u     /* lzs_decompress(): compressed bytes */
 #define INC_DEC_HOST_MAX     65536u     /* lzs_decompress_incremental(): a call's input bytes */
-#define INC_ENC_HOST_MAX     32768u     /* lzs_*compress_incremental(): bytes a piece has to decide */
+#define INC_ENC_HOST_MAX     16384u     /* lzs_*compress_incremental(): bytes a piece has to decide */
 static inline int route_on_host(size_t n, size_t crossover)
 {
     const int r = lzs_env()->route;
@@ -142,6 +147,9 @@ typedef struct {                    /* a piece of a stream for lzs_decompress_in
 LZS_HIDDEN size_t stream_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, piece_t *pc);
 LZS_HIDDEN size_t hostcodec_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, piece_t *pc);   /* the same on the host; SIZE_MAX: out of memory */
 LZS_HIDDEN void hostcodec_decode_resume(lzs_dec_resume_t *st, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap);   /* lzs_decode_resume_kernel's contract */
+LZS_HIDDEN void hostcodec_decode_resume_fields(uint32_t *bitq, uint32_t *qlen, uint32_t *off, uint32_t *rem, uint32_t *extended,
+                                               uint8_t *hist, uint32_t *hist_len, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
+                                               uint32_t *in_used, uint32_t *out_made, uint32_t *status_out);
 LZS_HIDDEN size_t stream_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status);
 LZS_HIDDEN size_t stream_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n, int dev, int *status, int concat,
                                     dec_piece_t *dp);

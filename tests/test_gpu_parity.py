@@ -675,6 +675,24 @@ def test_multi_megabyte_single_stream():
     assert lzs.decompress(got, len(data)) == data
 
 
+def test_short_segments_leave_lanes_that_never_took_a_position(monkeypatch):
+    """Round 5's regression: a segment of a stream may hold fewer positions than the workgroup has lanes (256-byte segments;
+    a last segment of a few bytes; a piece of the incremental interface), so some lanes never take a position in SEARCH.
+    With "idle" told by a lane standing on its own position (the result stored when the walk has ended, not every step),
+    such a lane must start out as one whose walk HAS ended -- a key that is none, not 0 -- or it wanders off along
+    garbage links and SEARCH never ends: the single-stream file tool hung on 313 KB.  Every segment size from the
+    smallest, lengths that leave 1..300 bytes in the last segment."""
+    blob = workload.fill("text", 6).tobytes()
+    for seg in (256, 512, 1024):
+        monkeypatch.setenv("LZS_STREAM_SEG", str(seg))
+        monkeypatch.setenv("LZS_FORCE_STREAM", "1")
+        for n in (1, 2, 17, 255, 256, 257, 300, 6145, 6145 + 77, 40000 + 1, 65536 + 255, 312778):
+            d = blob[:n]
+            assert lzs.compress(d) == O.compress(d), (seg, n)
+    monkeypatch.delenv("LZS_STREAM_SEG")
+    monkeypatch.delenv("LZS_FORCE_STREAM")
+
+
 def test_one_long_stream_on_many_workgroups_vs_oracle():
     """lzs_compress() of a buffer of 6 KiB or more is cut into segments (0.5-64 KiB), one workgroup
     each, stitched at the bit level.  Same bytes as the reference: every class,

@@ -5,6 +5,9 @@ WL=${2:-text}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# one variant of the kernel per launch, the one that class's blocks get (round 5: a launch of the library runs the classifier and
+# up to three variants over the same grid; the counters are the dominant kernel's)
+case $WL in lowent) export LZS_VARIANT=few;; random) export LZS_VARIANT=lit;; *) export LZS_VARIANT=text;; esac
 cd /tmp
 run() { # name, counters...
   name=$1; shift

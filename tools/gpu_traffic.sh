@@ -10,6 +10,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for WL in text lowent random; do
+  # (one variant of the kernel per launch, the one that class's blocks get: see tools/gpu_pmc.sh)
+  case $WL in lowent) export LZS_VARIANT=few;; random) export LZS_VARIANT=lit;; *) export LZS_VARIANT=text;; esac
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/${WL}_$C
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${WL}_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-stream --no-config5 --no-other-classes --workload $WL > $OUT/${WL}_$C.log 2>&1
