@@ -57,12 +57,14 @@ namespace wgv_safe {
 }
 #ifndef LZS_ONE_VARIANT      // (tools/probes/ab.sh -DLZS_ONE_VARIANT: the default alone, for the probes that launch it directly)
 namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- a sixth workgroup per CU
-#define LZS_WGV_HEAD3 768
-#define LZS_WGV_HEAD2 512
+#define LZS_WGV_HEAD3 768     // (PACK chunk by chunk: the one-pass form takes 81 vector registers, and the sixth wave per SIMD
+#define LZS_WGV_HEAD2 512     // is there up to 80; these blocks have few tokens to format anyway)
+#define LZS_WGV_PACK_BY_CHUNK 1
 #include "kernels/compress_wg.inc"
 }
-namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop
+namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop, PACK chunk by chunk
 #define LZS_WGV_SUBSTEPS 1
+#define LZS_WGV_PACK_BY_CHUNK 1
 #include "kernels/compress_wg.inc"
 }
 #endif
@@ -160,11 +162,10 @@ int lzs_hip_memset(void *d, int v, size_t n, void *st)
 // Asked once per device: lzs_lds_order_check_kernel over 16384 conflict patterns (~0.1 ms); a device
 // that fails it -- or LZS_CHAIN_FALLBACK=1 -- gets the slower form, with a note on stderr.
 static int g_chain_mode[64];            // 0 = not asked yet, else mode + 1
-// What the classifier of the launch before found (compress_aux.inc): 8 slots of {counts of the three classes, ticket} on the
-// device, taken in turn by the launches, and the counts of the last classifier that finished in pinned host memory.  Made
-// with the LDS ordering check, once per device; without them (an allocation failed) every launch runs all three variants.
-struct ClassHint { uint32_t *d_cnt; uint32_t *h_last; uint32_t mask_last, mask_prev, last_id; };
-static ClassHint g_hint[64];
+// What the classifiers of recent launches found (compress_aux.inc): four words of pinned host memory per device, h_seen[c] =
+// the id of the last launch a sampled workgroup of which met a block of class c.  Made with the LDS ordering check, once per
+// device; without them (the allocation failed) every launch runs all three variants.
+static uint32_t *g_hint_seen[64];
 static unsigned g_hint_launch;
 int lzs_hip_chain_mode(void *stream, int *mode)
 {
@@ -199,17 +200,13 @@ int lzs_hip_chain_mode(void *stream, int *mode)
             (void)hipStreamDestroy(own);
             if (e != hipSuccess) return (int)e;
             m = bad ? 2 : 1;
-            if (!bad && !g_hint[dev].d_cnt) {
-                uint32_t *d_cnt = nullptr, *h_last = nullptr;
-                if (hipMalloc((void **)&d_cnt, 8 * 4 * sizeof(uint32_t)) == hipSuccess &&
-                    hipMemset(d_cnt, 0, 8 * 4 * sizeof(uint32_t)) == hipSuccess &&
-                    hipHostMalloc((void **)&h_last, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) {
-                    h_last[0] = h_last[1] = h_last[2] = h_last[3] = 0;
-                    g_hint[dev].h_last = h_last;
-                    g_hint[dev].d_cnt = d_cnt;
+            if (!bad && !g_hint_seen[dev]) {
+                uint32_t *h_seen = nullptr;
+                if (hipHostMalloc((void **)&h_seen, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) {
+                    h_seen[0] = h_seen[1] = h_seen[2] = h_seen[3] = 0;
+                    __atomic_store_n(&g_hint_seen[dev], h_seen, __ATOMIC_RELEASE);
                 } else {
                     (void)hipGetLastError();
-                    if (d_cnt) (void)hipFree(d_cnt);
                 }
             }
             if (bad)
@@ -347,31 +344,22 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
     else if (forced == 2) LZS_LAUNCH_VARIANT(wgv_few, 0u);
     else if (forced == 3) LZS_LAUNCH_VARIANT(wgv_lit, 0u);
     else if (forced == 0 && nblocks >= kClassifyMinBlocks) {
-        // the variants the launch before had blocks for (all three while nothing is known); the rest go to the one that had most
+        // the variants recent launches had blocks for (all three while nothing is known); a block of another class goes to the default
+        // variant if that runs, else to the first that does
         int dev = 0;
-        uint32_t allow = 0xEu, catch_all = 1u, *d_cnt = nullptr, *h_last = nullptr;
-        const unsigned id = __atomic_add_fetch(&g_hint_launch, 1u, __ATOMIC_RELAXED);
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && g_hint[dev].d_cnt) {
-            h_last = g_hint[dev].h_last;
-            d_cnt = g_hint[dev].d_cnt + 4u * (id & 7u);
-            const uint32_t c1 = __atomic_load_n(&h_last[0], __ATOMIC_RELAXED), c2 = __atomic_load_n(&h_last[1], __ATOMIC_RELAXED),
-                           c3 = __atomic_load_n(&h_last[2], __ATOMIC_RELAXED);
-            if (c1 | c2 | c3) {
-                catch_all = c1 >= c2 && c1 >= c3 ? 1u : (c2 >= c3 ? 2u : 3u);
-                const uint32_t now = (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (c3 ? 8u : 0u);
-                // (and what the classifier before THAT one found: batches of two kinds in turn get both their variants)
-                const uint32_t lid = __atomic_load_n(&h_last[3], __ATOMIC_ACQUIRE);
-                if (lid != __atomic_load_n(&g_hint[dev].last_id, __ATOMIC_RELAXED)) {      // (a classifier has finished since the last look)
-                    __atomic_store_n(&g_hint[dev].mask_prev, __atomic_load_n(&g_hint[dev].mask_last, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
-                    __atomic_store_n(&g_hint[dev].mask_last, now, __ATOMIC_RELAXED);
-                    __atomic_store_n(&g_hint[dev].last_id, lid, __ATOMIC_RELAXED);
-                }
-                allow = now | __atomic_load_n(&g_hint[dev].mask_prev, __ATOMIC_RELAXED);
+        uint32_t allow = 0xEu, catch_all = 1u, *h_seen = nullptr;
+        const uint32_t id = (uint32_t)__atomic_add_fetch(&g_hint_launch, 1u, __ATOMIC_RELAXED) | 0x80000000u;      // (never 0)
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && (h_seen = __atomic_load_n(&g_hint_seen[dev], __ATOMIC_ACQUIRE)) != nullptr) {
+            uint32_t s[4], newest = 0;
+            for (int c = 1; c <= 3; c++) { s[c] = __atomic_load_n(&h_seen[c], __ATOMIC_RELAXED); if (s[c] && (newest == 0 || (int32_t)(s[c] - newest) > 0)) newest = s[c]; }
+            if (newest) {
+                allow = 0;
+                for (int c = 1; c <= 3; c++) if (s[c] && newest - s[c] <= 2u) allow |= 1u << c;       // (seen by one of the last three classifiers)
+                catch_all = (allow & 2u) ? 1u : ((allow & 4u) ? 2u : 3u);
             }
-            if (hipMemsetAsync(d_cnt, 0, 4 * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); d_cnt = nullptr; }
         }
         hipLaunchKernelGGL(lzs_classify_blocks_kernel, dim3((nblocks + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, d_out_len,
-                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, allow, catch_all, d_cnt, h_last, (uint32_t)id);
+                           (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, allow, catch_all, h_seen, id);
         if (allow & 2u) LZS_LAUNCH_VARIANT(wgv_text, kClassCode | 1u);
         if (allow & 4u) LZS_LAUNCH_VARIANT(wgv_few, kClassCode | 2u);
         if (allow & 8u) LZS_LAUNCH_VARIANT(wgv_lit, kClassCode | 3u);
@@ -397,7 +385,7 @@ int lzs_hip_classify_blocks(uint32_t *d_codes, const void *d_in, size_t in_strid
 {
     if (nblocks == 0) return 0;
     hipLaunchKernelGGL(lzs_classify_blocks_kernel, dim3((nblocks + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, d_codes,
-                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 0xEu, 1u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+                       (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 0xEu, 1u, (uint32_t *)nullptr, 0u);
     return (int)hipGetLastError();
 }
 

@@ -4,13 +4,21 @@
 #include KSRC
 #include <vector>
 #include <cstring>
+#include <string>
 extern "C" int lzs_workload_fill(uint8_t *, unsigned, uint64_t, uint64_t, size_t, size_t, int);
 int main(int argc, char **argv)
 {
     const unsigned cls = argc > 1 ? atoi(argv[1]) : 0;
     const uint32_t nb = argc > 2 ? atoi(argv[2]) : 16384, bl = 65536;
     std::vector<uint8_t> h((size_t)nb * bl);
-    lzs_workload_fill(h.data(), cls, 0x4C5A5331ull, 0, nb, bl, 32);
+    // (the generated input is shared with ab_bench through /tmp: the runs of one session generate it once)
+    const std::string cache = "/tmp/lzs_ab_class" + std::to_string(cls) + "_" + std::to_string(nb) + ".bin";
+    bool have = false;
+    if (FILE *f = fopen(cache.c_str(), "rb")) { have = fread(h.data(), 1, h.size(), f) == h.size(); fclose(f); }
+    if (!have) {
+        lzs_workload_fill(h.data(), cls, 0x4C5A5331ull, 0, nb, bl, 32);
+        if (FILE *f = fopen((cache + ".tmp").c_str(), "wb")) { const bool ok = fwrite(h.data(), 1, h.size(), f) == h.size(); fclose(f); if (ok) rename((cache + ".tmp").c_str(), cache.c_str()); }
+    }
     uint8_t *d_in, *d_out, *d_back; uint32_t *d_len, *d_blen;
     const size_t stride = 73744;
     hipMalloc(&d_in, h.size()); hipMalloc(&d_out, (size_t)nb * stride); hipMalloc(&d_len, nb * 4);
