@@ -13,11 +13,15 @@
  *
  * A program written against the reference's one-shot calls recompiles against
  * this header and links with -llzs unchanged; the work happens in hand-written
- * HIP kernels on the GPU (there is no CPU codec in this library).  The
+ * HIP kernels on the GPU, and without a GPU every call fails loudly (there is no
+ * fallback).  Small calls -- buffers of a few KiB, the incremental calls at the
+ * reference tools' 512-byte reads -- are served by the calling thread on a box
+ * that has its device, where one host core is faster than a launch and its wait;
+ * LZS_ROUTE=device|host in the environment forces either.  The
  * reference's incremental entry points (lzs.h:220-232) are declared at the end of
- * this header; each call is served by the device as well.  Batch and
- * device-pointer entry points, which the reference does not have, are in
- * <lzs/lzs_batch.h>.
+ * this header.  Batch and device-pointer entry points, which the reference does
+ * not have, are in <lzs/lzs_batch.h>; the partition and the RCCL moves of a job
+ * sharded over the GPUs of a node in <lzs/lzs_shard.h>.
  */
 #ifndef LZS_MI355X_LZS_H
 #define LZS_MI355X_LZS_H

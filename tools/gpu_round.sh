@@ -5,10 +5,10 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -5 | tee $OUT/pytest_gpu.txt
 # ... and once more the way a production process runs the library: the environment read once (no LZS_DEV_ENV), every call on the
 # device; the tests that flip a switch of the library skip themselves (tests/conftest.py)
-LZS_TEST_CACHED_ENV=1 LZS_ROUTE=device timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu_cached_env.txt
+LZS_TEST_CACHED_ENV=1 LZS_ROUTE=device timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -5 | tee $OUT/pytest_gpu_cached_env.txt
 timeout 600 python bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 | tee $OUT/bench_text.json
 timeout 300 python bench.py --steps 10 --warmup 2 --workload lowent --no-config5 --no-other-classes 2>/dev/null | tail -1 | tee $OUT/bench_lowent.json
 timeout 300 python bench.py --steps 10 --warmup 2 --workload random --no-config5 --no-other-classes 2>/dev/null | tail -1 | tee $OUT/bench_random.json
