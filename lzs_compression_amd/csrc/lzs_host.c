@@ -179,7 +179,7 @@ static void staging_destroy(void *p)
     for (int i = 0; i < PIPE_STREAMS; i++) if (st->pipe_stream[i]) lzs_hip_stream_destroy(st->pipe_stream[i]);
     for (int i = 0; i < PIPE_EVENTS; i++) if (st->pipe_event[i]) lzs_hip_event_destroy(st->pipe_event[i]);
     for (int i = 0; i < 6; i++) if (st->pin[i]) lzs_hip_host_free(st->pin[i]);
-    free(st->hostcodec);
+    hostcodec_free(st->hostcodec);
     free(st);
 }
 

@@ -35,6 +35,7 @@ typedef struct {
     uint32_t head2[65536];              /* base + position of the latest position with exactly these 2 bytes */
     uint16_t link3[2048];               /* per position & 2047: distance to the one before it on its 3-byte chain */
     uint32_t base;                      /* what this call adds to its positions: above everything stored so far */
+    uint8_t *scratch; size_t scratch_cap;   /* a piece's [history | input] as one array (grown as needed, freed with the tables) */
 } hc_tables_t;
 
 static uint32_t hc_hash3(const uint8_t *p)
@@ -61,6 +62,14 @@ static hc_tables_t *hc_tables(size_t span)
         t->base = HC_WINDOW + 1u;
     }
     return t;
+}
+
+LZS_HIDDEN void hostcodec_free(void *tables)
+{
+    hc_tables_t *t = (hc_tables_t *)tables;
+    if (!t) return;
+    free(t->scratch);
+    free(t);
 }
 
 /* ---- MSB-first bit sink; bytes past `cap` are counted, not stored (lzs-compression.c:304-313, 456-465) */
@@ -188,14 +197,19 @@ LZS_HIDDEN size_t hostcodec_compress(uint8_t *out, size_t cap, const uint8_t *in
  * c_exit, ext_exit, nbits (bit0 included, end marker not); returns the bytes of out[] that hold bits. */
 LZS_HIDDEN size_t hostcodec_compress_piece(uint8_t *out, size_t cap, const uint8_t *in, size_t n, piece_t *pc)
 {
-    uint8_t stack[24576];
-    uint8_t *d = stack;
     const size_t pre = pc->prefix_len;
-    if (n + 16u > sizeof stack) { d = (uint8_t *)malloc(n + 16u); if (!d) return SIZE_MAX; }
+    hc_tables_t *t = hc_tables(n);
+    if (!t) return SIZE_MAX;
+    /* (not on the caller's stack: the reference's one-shot compressor takes ~12 KiB of it, lzs-compression.c:253-254, and a
+     * program sized for that should not meet 24 KiB here) */
+    if (t->scratch_cap < n + 16u) {
+        uint8_t *grown = (uint8_t *)realloc(t->scratch, n + 4096u);
+        if (!grown) return SIZE_MAX;
+        t->scratch = grown; t->scratch_cap = n + 4096u;
+    }
+    uint8_t *d = t->scratch;
     if (pre) memcpy(d, pc->prefix, pre);
     memcpy(d + pre, in, n - pre);
-    hc_tables_t *t = hc_tables(n);
-    if (!t) { if (d != stack) free(d); return SIZE_MAX; }
     hc_sink_t s = { out, cap, 0, 0, 0 };
     if (pc->bit0) { s.acc = (uint64_t)pc->first >> (8u - pc->bit0); s.pending = pc->bit0; }
     const int closing = pc->last || pc->stop;                   /* the data is known to end at n */
@@ -243,7 +257,6 @@ LZS_HIDDEN size_t hostcodec_compress_piece(uint8_t *out, size_t cap, const uint8
         }
     }
     t->base += (uint32_t)n + HC_WINDOW + 1u;
-    if (d != stack) free(d);
     return result < cap ? result : cap;
 }
 

@@ -106,6 +106,7 @@ static inline int route_on_host(size_t n, size_t crossover)
 }
 LZS_HIDDEN size_t hostcodec_compress(uint8_t *out, size_t cap, const uint8_t *in, size_t n);      /* SIZE_MAX: out of memory */
 LZS_HIDDEN size_t hostcodec_decompress(uint8_t *out, size_t cap, const uint8_t *in, size_t n);
+LZS_HIDDEN void hostcodec_free(void *tables);            /* a thread's tables and scratch (staging_destroy) */
 
 /* thresholds of the one-shot calls */
 #define STREAM_MIN     6144u        /* shorter inputs are compressed by one workgroup (4 KiB: 0.109 ms alone, 0.127 in segments; 8 KiB: 0.167 / 0.127) */

@@ -252,6 +252,33 @@ def test_the_blocks_of_the_three_classes_get_their_variants_and_mixed_batches_st
         assert int(n[b]) == len(want) and out[b, :n[b]].tobytes() == want, (b, lens[b])
 
 
+def test_batches_of_changing_classes_follow_the_launches_before_and_stay_exact():
+    """Which variants of the compress kernel a launch runs follows what the classifiers of the launches before it met
+    (three words of pinned host memory, read without waiting): a block whose class has no variant in the launch goes to
+    the default's.  That guess can be slow, never wrong: batches of one class after the other, back and forth, mixed,
+    with the device left no time between them and with a wait after each -- every block against the oracle."""
+    nb = 128
+    parts = {c: workload.fill(c, nb) for c in workload.CLASS_NAMES}
+    mixed = np.stack([parts[workload.CLASS_NAMES[b % 3]][b // 3] for b in range(nb)])
+    want = {c: [O.compress(parts[c][b].tobytes()) for b in range(0, nb, 9)] for c in workload.CLASS_NAMES}
+    want["mixed"] = [O.compress(mixed[b].tobytes()) for b in range(0, nb, 9)]
+    dev = {c: torch.from_numpy(parts[c]).cuda() for c in workload.CLASS_NAMES}
+    dev["mixed"] = torch.from_numpy(mixed).cuda()
+    order = ["text", "text", "lowent", "lowent", "random", "text", "lowent", "text", "mixed", "random", "random", "mixed", "lowent"]
+    for wait in (True, False):
+        results = []
+        for name in order * 2:
+            slots, lens = lzs.compress_blocks(dev[name])
+            if wait:
+                torch.cuda.synchronize()
+            results.append((name, slots, lens))
+        torch.cuda.synchronize()
+        for name, slots, lens in results:
+            out, n = slots.cpu().numpy(), lens.cpu().numpy()
+            for k, b in enumerate(range(0, nb, 9)):
+                assert int(n[b]) == len(want[name][k]) and out[b, :n[b]].tobytes() == want[name][k], (wait, name, b)
+
+
 # ------------------------------------------------------------ differential vs the oracle
 def _fuzz_inputs(rng, count, maxlen):
     for _ in range(count):
