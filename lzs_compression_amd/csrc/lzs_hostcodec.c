@@ -119,7 +119,7 @@ static inline unsigned hc_search(const hc_tables_t *t, const uint8_t *d, size_t 
         uint32_t dist = at - t->head3[hc_hash3(d + c)];
         while (dist <= reach) {
             const uint8_t *q = d + c - dist;
-            if (q[best] == d[c + best] || best == lim) {         /* (longer than the best so far: its byte there must agree) */
+            if (q[best] == d[c + best]) {                        /* (longer than the best so far: its byte there must agree; best < lim here) */
                 const unsigned l = hc_lcp(d + c, q, lim);
                 if (l > best) { best = l; off = dist; if (l == lim) break; }
             }

@@ -204,7 +204,8 @@ int lzs_hip_chain_mode(void *stream, int *mode)
                 uint32_t *h_seen = nullptr;
                 if (hipHostMalloc((void **)&h_seen, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) {
                     h_seen[0] = h_seen[1] = h_seen[2] = h_seen[3] = 0;
-                    __atomic_store_n(&g_hint_seen[dev], h_seen, __ATOMIC_RELEASE);
+                    uint32_t *none = nullptr;         // (two threads asking at once: one set of words stays)
+                    if (!__atomic_compare_exchange_n(&g_hint_seen[dev], &none, h_seen, false, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) (void)hipHostFree(h_seen);
                 } else {
                     (void)hipGetLastError();
                 }
