@@ -48,15 +48,17 @@ namespace {
 // order-independent CHAIN for a device that fails the LDS ordering check, and the two a block's class may ask for.
 namespace wgv_text {
 #define LZS_WGV_SEGMENTS 1
+#define LZS_WGV_PRIO 1
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_safe {
 #define LZS_WGV_CHAIN_SAFE 1
 #define LZS_WGV_SEGMENTS 1
+#define LZS_WGV_PRIO 1
 #include "kernels/compress_wg.inc"
 }
 #ifndef LZS_ONE_VARIANT      // (tools/probes/ab.sh -DLZS_ONE_VARIANT: the default alone, for the probes that launch it directly)
-namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- a sixth workgroup per CU
+namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- a sixth workgroup per CU; no priorities (+0.2 %: noise)
 #define LZS_WGV_HEAD3 768     // (PACK chunk by chunk: the one-pass form takes 81 vector registers, and the sixth wave per SIMD
 #define LZS_WGV_HEAD2 512     // is there up to 80; these blocks have few tokens to format anyway)
 #define LZS_WGV_PACK_BY_CHUNK 1
@@ -65,6 +67,7 @@ namespace wgv_few {           // blocks of few distinct grams: long matches, the
 namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop, PACK chunk by chunk
 #define LZS_WGV_SUBSTEPS 1
 #define LZS_WGV_PACK_BY_CHUNK 1
+#define LZS_WGV_PRIO 1
 #include "kernels/compress_wg.inc"
 }
 #endif

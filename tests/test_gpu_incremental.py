@@ -27,11 +27,14 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 # the GPU whatever its size, the parity tests proper (-m gpu) -- and "host" -- LZS_ROUTE=host, the calling thread's own
 # codec (csrc/lzs_hostcodec.c) for every size, which needs no device and therefore runs in the CPU suite too.  The default
 # (by size) is a mix of the two that switches at the crossovers; tests/test_routes.py covers the switch itself.
-@pytest.fixture(autouse=True, params=[pytest.param("device", marks=pytest.mark.gpu), "host"])
+@pytest.fixture(autouse=True, params=[pytest.param("device", marks=pytest.mark.gpu), "host", pytest.param("by-size", marks=pytest.mark.gpu)])
 def route(request, monkeypatch):
-    if request.param == "device" and not torch.cuda.is_available():
+    if request.param != "host" and not torch.cuda.is_available():
         pytest.fail("the device route needs a GPU (it has no fallback)")
-    monkeypatch.setenv("LZS_ROUTE", request.param)
+    if request.param == "by-size":                    # what a caller gets: a stream changes route from call to call with the size of its pieces
+        monkeypatch.delenv("LZS_ROUTE", raising=False)
+    else:
+        monkeypatch.setenv("LZS_ROUTE", request.param)
     return request.param
 
 
