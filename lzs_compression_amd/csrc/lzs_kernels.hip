@@ -62,6 +62,7 @@ namespace wgv_few {           // blocks of few distinct grams: long matches, the
 #define LZS_WGV_HEAD3 768     // (PACK chunk by chunk: the one-pass form takes 81 vector registers, and the sixth wave per SIMD
 #define LZS_WGV_HEAD2 512     // is there up to 80; these blocks have few tokens to format anyway)
 #define LZS_WGV_PACK_BY_CHUNK 1
+#define LZS_WGV_LEAN 1
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop, PACK chunk by chunk
