@@ -19,6 +19,7 @@ int         lzs_hip_device_count(int *count);
 int         lzs_hip_describe(char *buf, size_t cap);          /* "hip gfx950 ..., N CUs, ..." */
 const char *lzs_hip_strerror(int hip_error);
 
+int lzs_hip_total_memory(size_t *bytes);             /* the current device's memory */
 int lzs_hip_malloc(void **p, size_t bytes);
 int lzs_hip_free(void *p);
 int lzs_hip_stream_create(void **stream);

@@ -160,7 +160,7 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
 /* ------------------------------------------------- per-thread staging (host batches) */
 /* Each host thread keeps one HIP stream and four grow-only device buffers for the host-buffer
  * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
- * released when the thread exits; buffers above KEEP_MAX are released right after the call. */
+ * released when the thread exits; buffers above keep_max() are released right after the call. */
 #define KEEP_MAX ((size_t)640 << 20)
 
 
@@ -226,7 +226,7 @@ static void env_read(lzs_env_t *e)
     const char *v;
     memset(e, 0, sizeof *e);
     v = get("LZS_KEEP_MAX_MB");
-    { const unsigned long mb = v ? strtoul(v, NULL, 10) : 0; e->keep_max = mb ? (size_t)mb << 20 : KEEP_MAX; }
+    { const unsigned long mb = v ? strtoul(v, NULL, 10) : 0; e->keep_max = (size_t)mb << 20; }   /* (0: keep_max() below has the default) */
     e->one_wave = get("LZS_ONE_WAVE") != NULL;
     e->one_workgroup = get("LZS_ONE_WORKGROUP") != NULL;
     e->force_stream = get("LZS_FORCE_STREAM") != NULL;
@@ -261,9 +261,25 @@ LZS_HIDDEN const lzs_env_t *lzs_env(void)
     return &fresh;
 }
 
-/* Buffers above the limit are released right after the call (LZS_KEEP_MAX_MB overrides the
- * default of 640 MiB per buffer -- KEEP_MAX -- for programs that compress large buffers over and over). */
-static size_t keep_max(void) { return lzs_env()->keep_max; }
+/* Buffers above the limit are released right after the call.  The default is 1/64 of the device's memory per buffer and no
+ * less than 640 MiB (4.5 GiB on a 288 GiB MI355X: a 1 GiB stream's table of origins, 4 GiB, stays) -- a hipMalloc of
+ * gigabytes is not a cheap call: 0.2 ms most of the time and 0.24-1.3 s now and then (profiles/r05/malloc_time.txt,
+ * stream_decode_glitch.txt), which a program that decodes large streams over and over would pay again and again.
+ * LZS_KEEP_MAX_MB overrides it. */
+static size_t keep_max(void)
+{
+    const size_t from_env = lzs_env()->keep_max;
+    if (from_env) return from_env;
+    static size_t dflt;                                  /* (the same value whichever thread gets there first) */
+    size_t d = __atomic_load_n(&dflt, __ATOMIC_RELAXED);
+    if (!d) {
+        size_t total = 0;
+        d = KEEP_MAX;
+        if (lzs_hip_total_memory(&total) == 0 && total / 64 > d) d = total / 64;
+        __atomic_store_n(&dflt, d, __ATOMIC_RELAXED);
+    }
+    return d;
+}
 
 LZS_HIDDEN int staging_pin_reserve(staging_t *st, int which, size_t bytes, uint8_t **out)
 {

@@ -31,7 +31,7 @@ LZS_HIDDEN int require_device(void);
  * entry points ask a struct, not getenv().  LZS_DEV_ENV=1 (set before the first call: the test suites do)
  * makes every lzs_env() read the environment afresh, so a test can flip a switch between two calls. */
 typedef struct {
-    size_t   keep_max;              /* LZS_KEEP_MAX_MB: staging buffers above it are released after the call */
+    size_t   keep_max;              /* LZS_KEEP_MAX_MB: staging buffers above it are released after the call; 0: the default (lzs_host.c) */
     int      one_wave, one_workgroup, force_stream;
     uint32_t stream_seg, dec_seg;   /* LZS_STREAM_SEG, LZS_DEC_SEG (0: by size) */
     int      stream_debug, no_marks, no_ones, verify_scan, no_tails, no_chunks;

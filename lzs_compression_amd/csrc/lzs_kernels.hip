@@ -111,6 +111,13 @@ int lzs_hip_describe(char *buf, size_t cap)
     return 0;
 }
 
+int lzs_hip_total_memory(size_t *bytes)
+{
+    size_t free_b = 0, total = 0;
+    const hipError_t e = hipMemGetInfo(&free_b, &total);
+    if (e == hipSuccess) *bytes = total;
+    return (int)e;
+}
 int lzs_hip_malloc(void **p, size_t bytes) { return (int)hipMalloc(p, bytes ? bytes : 1); }
 int lzs_hip_free(void *p) { return (int)hipFree(p); }
 int lzs_hip_host_malloc(void **p, size_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault); }

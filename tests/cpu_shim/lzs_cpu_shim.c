@@ -41,6 +41,7 @@ int lzs_hip_device_count(int *count) { *count = 1; return 0; }
 int lzs_hip_describe(char *buf, size_t cap) { snprintf(buf, cap, "cpu shim (tests/cpu_shim): the oracle behind the launchers, synchronous streams"); return 0; }
 const char *lzs_hip_strerror(int e) { return e == E_NOT_SUPPORTED ? "operation not supported (cpu shim)" : e == E_OUT_OF_MEMORY ? "out of memory (cpu shim)" : e ? "error (cpu shim)" : "no error"; }
 
+int lzs_hip_total_memory(size_t *bytes) { *bytes = (size_t)8 << 30; return 0; }    /* (1/64 of it is below the library's floor of 640 MiB) */
 int lzs_hip_malloc(void **p, size_t bytes)
 {
     if (bytes > ((size_t)1 << 40)) { *p = NULL; g_last_error = E_OUT_OF_MEMORY; return E_OUT_OF_MEMORY; }
