@@ -38,6 +38,7 @@ __global__ void k_time(uint64_t *out, uint32_t stride, uint32_t shift)
         if (W == 8) { asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:64\n ds_read_b64 %0, %2 offset:128\n ds_read_b64 %1, %2 offset:192\n s_waitcnt lgkmcnt(0)" : "=v"(b0), "=v"(b1) : "v"(addr) : "memory"); acc += (uint32_t)b0 + (uint32_t)b1; }
         if (W == 12) { asm volatile("ds_read_b96 %0, %2\n ds_read_b96 %1, %2 offset:64\n ds_read_b96 %0, %2 offset:128\n ds_read_b96 %1, %2 offset:192\n s_waitcnt lgkmcnt(0)" : "=v"(c0), "=v"(c1) : "v"(addr) : "memory"); acc += c0.x + c1.z; }
         if (W == 16) { asm volatile("ds_read2_b32 %0, %2 offset1:1\n ds_read2_b32 %1, %2 offset0:2 offset1:3\n ds_read2_b32 %0, %2 offset0:16 offset1:17\n ds_read2_b32 %1, %2 offset0:18 offset1:19\n s_waitcnt lgkmcnt(0)" : "=v"(b0), "=v"(b1) : "v"(addr) : "memory"); acc += (uint32_t)b0 + (uint32_t)b1; }
+        if (W == 128) { typedef uint32_t u4 __attribute__((ext_vector_type(4))); u4 d0, d1; asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:64\n ds_read_b128 %0, %2 offset:128\n ds_read_b128 %1, %2 offset:192\n s_waitcnt lgkmcnt(0)" : "=v"(d0), "=v"(d1) : "v"(addr) : "memory"); acc += d0.x + d1.w; }
     }
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
     if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
@@ -63,10 +64,10 @@ int main()
                (uint8_t)((16 + shift) * 7 + 3), (uint8_t)((17 + shift) * 7 + 3), (uint8_t)((18 + shift) * 7 + 3), (uint8_t)((19 + shift) * 7 + 3));
     }
     printf("ticks per DS instruction and SIMD (4 waves per CU / 8 / 16), lane stride in bytes, address shift:\n");
-    for (uint32_t stride : {16u, 80u, 208u}) for (uint32_t shift : {0u, 1u, 2u}) {
+    for (uint32_t stride : {16u, 80u, 208u, 1040u}) for (uint32_t shift : {0u, 4u, 8u, 12u, 1u}) {
         printf("stride %3u shift %u:", stride, shift);
-        for (int W : {4, 8, 12, 16}) {
-            printf("  %s", W == 4 ? "b32" : W == 8 ? "b64" : W == 12 ? "b96" : "2x read2_b32");
+        for (int W : {4, 8, 12, 16, 128}) {
+            printf("  %s", W == 4 ? "b32" : W == 8 ? "b64" : W == 12 ? "b96" : W == 16 ? "2x read2_b32 (per pair)" : "b128");
             for (int wps = 1; wps <= 4; wps *= 2) {
                 uint64_t hh[16]; double best = 1e30;
                 for (int rep = 0; rep < 3; rep++) {
@@ -74,6 +75,7 @@ int main()
                     if (W == 8) hipLaunchKernelGGL(k_time<8>, dim3(1), dim3(256 * wps), 0, 0, t, stride, shift);
                     if (W == 12) hipLaunchKernelGGL(k_time<12>, dim3(1), dim3(256 * wps), 0, 0, t, stride, shift);
                     if (W == 16) hipLaunchKernelGGL(k_time<16>, dim3(1), dim3(256 * wps), 0, 0, t, stride, shift);
+                    if (W == 128) hipLaunchKernelGGL(k_time<128>, dim3(1), dim3(256 * wps), 0, 0, t, stride, shift);
                     if (hipDeviceSynchronize() != hipSuccess) { printf(" failed\n"); return 1; }
                     hipMemcpy(hh, t, sizeof hh, hipMemcpyDeviceToHost);
                     double mx = 0; for (int w = 0; w < 4 * wps; w++) mx = hh[w] > mx ? (double)hh[w] : mx;
