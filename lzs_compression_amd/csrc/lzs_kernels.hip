@@ -28,6 +28,12 @@
 //                          interface (3.7)
 // No MFMA anywhere: this is byte search and bit packing, not a contraction.
 //
+// The library compiles this file TWICE (csrc/Makefile): -DLZS_TU_COMPRESS at -Os -fno-unroll-loops -- the compress kernel's
+// 15 KB of code are run by five workgroups per CU at five different places, and smaller is faster there -- and
+// -DLZS_TU_DECOMPRESS at -O3 -fno-unroll-loops, which the decoders' one loop prefers by 2-4 % (profiles/r05/
+// abdec_s27_optimisation_levels.txt).  Each half leaves the other's kernels and launchers out; with neither macro (the probes
+// of tools/probes/, which include this file) everything is in.
+//
 // gfx950 only.  No CUDA compatibility layer, no alternate code paths.
 
 #include <hip/hip_runtime.h>
@@ -41,6 +47,7 @@
 namespace {
 
 #include "kernels/common.inc"
+#ifndef LZS_TU_DECOMPRESS
 #ifdef LZS_WITH_VARIANTS   // the earlier compressors ("chain", "scan") and the v1 decoder: A/B builds only
 #include "compress_variants.inc"                 // tools/variants/ (the Makefile adds the path for liblzs_variants.so only)
 #endif
@@ -75,9 +82,14 @@ namespace wgv_lit {           // blocks that are nearly all literals: one full s
 using wgv_text::lzs_compress_blocks_wg_kernel;        // (what tools/probes/ launch by name)
 using wgv_text::kWgThreads;
 #include "kernels/compress_aux.inc"
+#endif  // !LZS_TU_DECOMPRESS
+#ifndef LZS_TU_COMPRESS
 #include "kernels/decompress_blocks.inc"
 #include "kernels/decompress_stream.inc"
+#endif
+#ifndef LZS_TU_DECOMPRESS
 #include "kernels/compact_resume.inc"
+#endif
 
 }  // namespace
 
@@ -85,6 +97,7 @@ using wgv_text::kWgThreads;
 // extern "C" shim (see lzs_hip_shim.h)
 // =====================================================================================
 extern "C" {
+#ifndef LZS_TU_DECOMPRESS
 
 int lzs_hip_device_count(int *count) { return (int)hipGetDeviceCount(count); }
 
@@ -401,6 +414,8 @@ int lzs_hip_classify_blocks(uint32_t *d_codes, const void *d_in, size_t in_strid
     return (int)hipGetLastError();
 }
 
+#endif  // !LZS_TU_DECOMPRESS
+#ifndef LZS_TU_COMPRESS
 static int launch_decompress(void *d_out, size_t out_stride, uint32_t out_cap, uint32_t *d_out_len,
                              const void *d_in, size_t in_stride, const uint32_t *d_in_len,
                              uint32_t in_len, uint32_t nblocks, void *stream, uint32_t concat)
@@ -451,6 +466,8 @@ int lzs_hip_launch_decompress_concat(void *d_out, size_t out_stride, uint32_t ou
     return launch_decompress(d_out, out_stride, out_cap, d_out_len, d_in, in_stride, d_in_len, in_len, nblocks, stream, 1);
 }
 
+#endif  // !LZS_TU_COMPRESS
+#ifndef LZS_TU_DECOMPRESS
 int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const void *d_in, uint32_t n,
                                      uint32_t seg, uint32_t nseg, const uint32_t *d_entry,
                                      const uint8_t *d_dirty, uint32_t *d_exit, uint64_t *d_nbits,
@@ -493,6 +510,8 @@ int lzs_hip_launch_stitch_segments(void *d_out, const void *d_slots, size_t slot
     return (int)hipGetLastError();
 }
 
+#endif  // !LZS_TU_DECOMPRESS
+#ifndef LZS_TU_COMPRESS
 int lzs_hip_launch_scan_stream(const void *d_in, uint32_t n, uint32_t nseg, const uint32_t *d_entry,
                                const uint8_t *d_dirty, uint32_t *d_exit, uint32_t *d_count,
                                uint8_t *d_all_ones, uint32_t *d_marks, int compare, uint32_t seg, int concat,
@@ -602,6 +621,8 @@ int lzs_hip_launch_resolve_chunks(void *d_out, uint32_t *d_origin, uint32_t tota
 
 unsigned lzs_hip_dec_segment_bytes(void) { return kDecSegMax; }
 
+#endif  // !LZS_TU_COMPRESS
+#ifndef LZS_TU_DECOMPRESS
 int lzs_hip_launch_compact(void *d_dense, uint64_t *d_offsets, const void *d_slots,
                            size_t slot_stride, const uint32_t *d_len, uint32_t nblocks, void *stream)
 {
@@ -624,4 +645,5 @@ int lzs_hip_launch_decode_resume(lzs_dec_resume_t *d_state, const void *d_in, ui
     return (int)hipGetLastError();
 }
 
+#endif  // !LZS_TU_DECOMPRESS
 }  // extern "C"
