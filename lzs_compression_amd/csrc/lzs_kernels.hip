@@ -74,6 +74,7 @@ namespace wgv_few {           // blocks of few distinct grams: long matches, the
 }
 namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop, PACK chunk by chunk
 #define LZS_WGV_SUBSTEPS 1
+#define LZS_WGV_HOPS 3
 #define LZS_WGV_PACK_BY_CHUNK 1
 #define LZS_WGV_PRIO 1
 #include "kernels/compress_wg.inc"
