@@ -70,6 +70,7 @@ namespace wgv_few {           // blocks of few distinct grams: long matches, the
 #define LZS_WGV_HEAD2 512     // is there up to 80; these blocks have few tokens to format anyway)
 #define LZS_WGV_PACK_BY_CHUNK 1
 #define LZS_WGV_LEAN 1
+#define LZS_WGV_HOPS 0
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop, PACK chunk by chunk
