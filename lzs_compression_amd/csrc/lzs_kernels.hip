@@ -56,6 +56,8 @@ namespace {
 namespace wgv_text {
 #define LZS_WGV_SEGMENTS 1
 #define LZS_WGV_PRIO 1
+// (six workgroups per CU for THIS variant cost more in buckets than the sixth workgroup gives: 1024 / 512 buckets 72.6 GB/s,
+// 896 / 512 71.5, 1152 / 256 70.3, 768 / 1024 69.0 against 74.7 -- profiles/r05/ab_s41)
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_safe {
@@ -78,6 +80,11 @@ namespace wgv_lit {           // blocks that are nearly all literals: one full s
 #define LZS_WGV_HOPS 3
 #define LZS_WGV_PACK_BY_CHUNK 1
 #define LZS_WGV_PRIO 1
+#ifndef LZS_EXP_LIT6          // six workgroups per CU here too: the 3-byte chains of such blocks hold collisions whatever the table's
+#define LZS_EXP_LIT6 512      // size, and with 512 buckets (384 ... 544 measured alike, 576 is five workgroups again, 256 gives it
+#endif                        // back to collisions) the LDS is 26.7 KB: 99.3 -> 107.6 GB/s (profiles/r05/ab_s39, ab_s40)
+#define LZS_WGV_HEAD3 LZS_EXP_LIT6
+#define LZS_WGV_LEAN 1
 #include "kernels/compress_wg.inc"
 }
 #endif
