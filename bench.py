@@ -81,13 +81,14 @@ def kernel_identity() -> str:
     """SHA-256 over the sources the measured kernel, lzs_compress_blocks_wg_kernel, is compiled from
     (kernels/common.inc, kernels/compress_wg.inc and kernels/compress_aux.inc: its code in every variant, its LDS
     layout, its launch geometry -- one workgroup of kWgThreads per block -- and the classifier that gives a block its
-    variant): what a counter measurement belongs to.
+    variant; lzs_kernels.hip: what each variant's configuration is -- bucket counts, hops, sub-steps -- and the launcher):
+    what a counter measurement belongs to.
     (The decoders' sources are not part of it: the traffic figure is the compress kernel's.)"""
     import hashlib
-    csrc = os.path.join(ROOT, "lzs_compression_amd", "csrc", "kernels")
+    csrc = os.path.join(ROOT, "lzs_compression_amd", "csrc")
     h = hashlib.sha256()
-    for name in ("common.inc", "compress_wg.inc", "compress_aux.inc"):
-        h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
+    for name in ("kernels/common.inc", "kernels/compress_wg.inc", "kernels/compress_aux.inc", "lzs_kernels.hip"):
+        h.update(os.path.basename(name).encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()
 
 
