@@ -58,6 +58,15 @@ namespace wgv_text {
 #define LZS_WGV_PRIO 1
 // (six workgroups per CU for THIS variant cost more in buckets than the sixth workgroup gives: 1024 / 512 buckets 72.6 GB/s,
 // 896 / 512 71.5, 1152 / 256 70.3, 768 / 1024 69.0 against 74.7 -- profiles/r05/ab_s41)
+#ifdef LZS_EXP_TEXT_POOL     // (tools/probes/ab.sh experiments on the default variant's shape: round 6's pool of 256, its bucket count,
+#define LZS_WGV_POOL LZS_EXP_TEXT_POOL   // SEARCH's constants as literals)
+#endif
+#ifdef LZS_EXP_TEXT_HEAD3
+#define LZS_WGV_HEAD3 LZS_EXP_TEXT_HEAD3
+#endif
+#ifdef LZS_EXP_TEXT_LEAN
+#define LZS_WGV_LEAN 1
+#endif
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_safe {

@@ -45,6 +45,10 @@ int main(int argc, char **argv)
                    (double)p[9] / q, (double)p[10] / q, (double)p[14] / (p[9] ? p[9] : 1), (double)p[11] / q, (double)p[12] / (p[11] ? p[11] : 1), (double)p[15] / (p[11] ? p[11] : 1));
             printf("          build: %.0f cycles per batch of 64 incl. its barriers (%.2f batches per pool); cycles per pool: extend %.0f, doubling %.0f, [barrier], exit walk %.0f, tokens+encode+scan %.0f, [barrier], offsets+bits_or %.0f\n",
                    (double)p[16] / (p[17] ? p[17] : 1), (double)p[17] / q, p[20] / q, p[21] / q, p[23] / q, p[24] / q, p[26] / q);
+            // (round 6) the trip counts the instruction ledger needs (tools/ledger.py): per wave and pool
+            printf("          ledger trips per pool: rounds %.3f, ring refills %.3f, batches hashed+chained %.2f, refill passes %.3f (with the offset-1 length %.3f; %.3f that found nothing to take), step iterations %.3f, "
+                   "extend: chunks with a capped match %.3f, compare-loop trips %.3f; parse rounds %.3f, exit hops %.3f, quarters stored %.3f, second PACK passes %.3f\n",
+                   1.0, p[42] / q, (double)p[17] / q, (double)p[9] / q, p[18] / q, p[43] / q, (double)p[11] / q, p[19] / q, p[27] / q, p[31] / q, p[28] / q, p[29] / q, p[30] / q);
         }
     }
     return 0;
