@@ -77,6 +77,39 @@ def usable_cores() -> int:
     return cores
 
 
+def host_cpu() -> dict:
+    """The host the cpu_baseline ran on ("state the count and CPU model"): the model name, the physical
+    cores (distinct (package, core) pairs of /proc/cpuinfo), the logical CPUs of the affinity mask, and the cgroup's CPU
+    quota in cores (None: unlimited) -- `cores` of the baseline is the smaller of the last two, what the threads can use."""
+    model, pairs, phys, core = None, set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "physical_cores": len(pairs) or None,
+            "logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(), "quota_cores": quota}
+
+
 def kernel_identity() -> str:
     """SHA-256 over the sources the measured kernel, lzs_compress_blocks_wg_kernel, is compiled from
     (kernels/common.inc, kernels/compress_wg.inc and kernels/compress_aux.inc: its code in every variant, its LDS
@@ -133,6 +166,7 @@ def cpu_sample(blocks_host) -> tuple:
     _, _, secs1 = oracle.run_blocks(codec, blocks_host[:max(64, nsample // cores)], threads=1)
     one_core = max(64, nsample // cores) * BLOCK / secs1 / 1e9
     return ({"value": nsample * BLOCK / secs / 1e9, "unit": "GB/s", "cores": cores, "kind": kind,
+             **host_cpu(),
              "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity/cgroup quota)",
              "one_core_GBps": one_core,
              "sample": f"first {nsample} of the same 64 KiB blocks ({nsample * BLOCK >> 20} MiB), "
@@ -625,6 +659,10 @@ def run_sharded(args, dist, rank: int, world: int, dev) -> dict:
             "compute_only_GBps": total_in / co / 1e9,
             "scatter_GBps": (world - 1) * nb * BLOCK / sc / 1e9 if sc > 0 and world > 1 else None,
             "gather_GBps": (sum(job.counts) - job.counts[0]) / ga / 1e9 if ga > 0 and world > 1 else None,
+            # per xGMI link of the root: its N - 1 peers are served at once, one link each (DESIGN.md section 6 assumes
+            # 45-60 GB/s a link; point to point, 7 links x ~153 GB/s per GPU)
+            "scatter_GBps_per_link": nb * BLOCK / sc / 1e9 if sc > 0 and world > 1 else None,
+            "gather_GBps_per_link": (sum(job.counts) - job.counts[0]) / (world - 1) / ga / 1e9 if ga > 0 and world > 1 else None,
             "overlapped_step": {"comm_busy_ms": comm_busy * 1e3, "compute_busy_ms": comp_busy * 1e3,
                                 "stage_comm_ms_rank0_last_step": stage_ms.get("comm"), "stage_compute_ms_rank0_last_step": stage_ms.get("compute"),
                                 "note": "HIP events around every stage's batch of point-to-point operations (comm) and every "

@@ -16,8 +16,13 @@
  * HIP kernels on the GPU, and without a GPU every call fails loudly (there is no
  * fallback).  Small calls -- buffers of a few KiB, the incremental calls at the
  * reference tools' 512-byte reads -- are served by the calling thread on a box
- * that has its device, where one host core is faster than a launch and its wait;
- * LZS_ROUTE=device|host in the environment forces either.  The
+ * that has its device, where one host core is faster than a launch and its wait
+ * (the device is asked for once per process, at the first call, not before each
+ * small call); LZS_ROUTE=device in the environment keeps every call on the GPU.
+ * LZS_ROUTE=host is a development and test switch: it sends every size the host
+ * route can take (up to 1 GiB) to the calling thread and with that REMOVES the
+ * device requirement for those calls -- a CPU codec, not this library's product
+ * (DESIGN.md 3.9).  The
  * reference's incremental entry points (lzs.h:220-232) are declared at the end of
  * this header.  Batch and device-pointer entry points, which the reference does
  * not have, are in <lzs/lzs_batch.h>; the partition and the RCCL moves of a job

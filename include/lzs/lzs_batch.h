@@ -36,6 +36,17 @@ extern "C" {
 /* Message for the calling thread's most recent failure ("" if none). Never NULL. */
 const char *lzs_last_error(void);
 
+/*
+ * What the library keeps between calls, and how to get it back.  The reference keeps nothing after return (lzs.h:218,229:
+ * the caller's two buffers and some stack).  This build's host-buffer and one-shot calls stage through device memory, a
+ * stream and pinned pieces that belong to the CALLING THREAD and stay for its next call (a hipMalloc of gigabytes can
+ * take a second): at most LZS_KEEP_MAX_MB MiB of device memory in sum per thread (environment, read once per process;
+ * default: 1/32 of the device's memory, at least 640 MiB -- what is above it is freed before the call returns), released
+ * when the thread exits -- or now, by this call, from the thread that owns it.  The device-pointer calls
+ * (lzs_*_batch_device, lzs_compact_device) allocate nothing and keep nothing.
+ */
+void lzs_release_thread_cache(void);
+
 /* Human-readable description of the backend ("hip gfx950 ... 256 CUs ...") into buf.
  * Returns LZS_OK, or LZS_E_NO_DEVICE when there is no device (buf then holds the reason). */
 int lzs_backend_info(char *buf, size_t cap);
@@ -51,7 +62,8 @@ int lzs_backend_info(char *buf, size_t cap);
  * Each block is an independent LZS stream with its own end marker, i.e. the result of
  * lzs_compress(d_out + b*out_stride, out_cap, d_in + b*in_stride, len_b)
  * (reference lzs-compression.c:249-467).  All pointers are device pointers;
- * d_in_len may be NULL.  `hip_stream` is a hipStream_t passed as void* (NULL = the
+ * d_in_len may be NULL; it must not be the array d_out_len (LZS_E_ARG: d_out_len[] is
+ * scratch of the launch until a block's length lands there).  `hip_stream` is a hipStream_t passed as void* (NULL = the
  * default stream).  Fastest when d_in, in_stride are multiples of 16 and d_out,
  * out_stride multiples of 4; any alignment is accepted.  No allocation, no
  * synchronisation: safe to capture into a hipGraph.  (Once per device and process the

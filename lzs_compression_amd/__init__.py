@@ -7,11 +7,11 @@ fallback: without the built library or without a GPU, calls raise.
 """
 from .api import (IncrementalCompressor, IncrementalDecompressor, LzsError, backend_info, compact, compress, compress_batch, compress_blocks,
                   compress_stream, compressed_max, decompress, decompress_batch, decompress_blocks, decompress_blocks_sync, decompress_concat,
-                  decompress_stream, decompressed_max, incremental_compress, last_error, lib)
+                  decompress_stream, decompressed_max, incremental_compress, last_error, lib, release_thread_cache)
 from .api import (STATUS_END_MARKER, STATUS_ERROR, STATUS_INPUT_FINISHED, STATUS_INPUT_STARVED, STATUS_NO_OUTPUT_BUFFER_SPACE)
 from . import workload
 
 __all__ = ["IncrementalCompressor", "IncrementalDecompressor", "LzsError", "backend_info", "compact", "compress", "compress_batch", "compress_blocks",
            "compress_stream", "compressed_max", "decompress", "decompress_batch", "decompress_blocks", "decompress_blocks_sync", "decompress_concat",
-           "decompress_stream", "decompressed_max", "incremental_compress", "last_error", "lib", "workload",
+           "decompress_stream", "decompressed_max", "incremental_compress", "last_error", "lib", "release_thread_cache", "workload",
            "STATUS_END_MARKER", "STATUS_ERROR", "STATUS_INPUT_FINISHED", "STATUS_INPUT_STARVED", "STATUS_NO_OUTPUT_BUFFER_SPACE"]

@@ -66,6 +66,7 @@ def lib() -> ctypes.CDLL:
             f = getattr(L, name)
             f.restype, f.argtypes = _sz, [_vp, _sz, _vp, _sz]
         L.lzs_last_error.restype, L.lzs_last_error.argtypes = ctypes.c_char_p, []
+        L.lzs_release_thread_cache.restype, L.lzs_release_thread_cache.argtypes = None, []
         L.lzs_backend_info.restype, L.lzs_backend_info.argtypes = ctypes.c_int, [ctypes.c_char_p, _sz]
         for name in ("lzs_compress_batch_device", "lzs_decompress_batch_device"):
             f = getattr(L, name)
@@ -98,6 +99,12 @@ def last_error() -> str:
 def _check(rc: int) -> None:
     if rc != LZS_OK:
         raise LzsError(rc, last_error())
+
+
+def release_thread_cache() -> None:
+    """lzs_release_thread_cache(): what the CALLING THREAD's earlier host-buffer and one-shot calls left behind (device
+    staging, streams, pinned pieces) is given back now instead of when the thread exits (include/lzs/lzs_batch.h)."""
+    lib().lzs_release_thread_cache()
 
 
 def backend_info() -> str:

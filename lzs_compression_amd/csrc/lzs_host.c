@@ -78,6 +78,9 @@ static int device_batch(const char *who, launch_fn launch, void *d_out, size_t o
     int rc = check_batch(who, d_out_len, d_in, in_len, nblocks);
     if (rc != LZS_OK || nblocks == 0) return rc;
     if (!d_out && out_cap) return fail(LZS_E_ARG, "%s: output is NULL", who);
+    /* the lengths written are not the lengths read: a compress launch leaves every block's class in d_out_len[] before any
+     * workgroup reads d_in_len[] */
+    if (d_in_len && (const void *)d_in_len == (const void *)d_out_len) return fail(LZS_E_ARG, "%s: d_out_len and d_in_len are the same array", who);
     uint32_t cap32 = out_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)out_cap;
     int e = launch(d_out, out_stride, cap32, d_out_len, d_in, in_stride, d_in_len,
                    (uint32_t)in_len, (uint32_t)nblocks, stream);
@@ -158,9 +161,11 @@ int lzs_compact_device(void *d_dense, uint64_t *d_offsets, const void *d_slots, 
 }
 
 /* ------------------------------------------------- per-thread staging (host batches) */
-/* Each host thread keeps one HIP stream and four grow-only device buffers for the host-buffer
- * entry points, so a small one-shot call costs copies + a launch, not allocations.  They are
- * released when the thread exits; buffers above keep_max() are released right after the call. */
+/* Each host thread keeps one HIP stream and grow-only device buffers for the host-buffer
+ * entry points, so a small one-shot call costs copies + a launch, not allocations.  What a thread keeps between
+ * calls is at most keep_max() bytes of device memory IN SUM (staging_trim, after every call); all of it goes back when
+ * the thread exits or calls lzs_release_thread_cache().  (The reference keeps nothing after return -- it has nothing
+ * to keep: lzs.h:218,229 work on the caller's two buffers and ~12 KiB of stack; SURVEY.md 8(b) Ownership.) */
 #define KEEP_MAX ((size_t)640 << 20)
 
 
@@ -184,6 +189,18 @@ static void staging_destroy(void *p)
 }
 
 static void staging_make_key(void) { pthread_key_create(&staging_key, staging_destroy); }
+
+/* Everything the calling thread's earlier calls left behind -- device staging, its streams and events, pinned pieces, the
+ * host route's tables -- given back now instead of when the thread exits.  The thread's next call starts from nothing. */
+void lzs_release_thread_cache(void)
+{
+    pthread_once(&staging_once, staging_make_key);
+    staging_t *st = (staging_t *)pthread_getspecific(staging_key);
+    if (!st) return;
+    if (st->stream) lzs_hip_stream_sync(st->stream);          /* (nothing of this thread's is in flight between its calls; a failed call may have left work) */
+    pthread_setspecific(staging_key, NULL);
+    staging_destroy(st);
+}
 
 LZS_HIDDEN staging_t *staging_get(void)
 {
@@ -261,11 +278,12 @@ LZS_HIDDEN const lzs_env_t *lzs_env(void)
     return &fresh;
 }
 
-/* Buffers above the limit are released right after the call.  The default is 1/64 of the device's memory per buffer and no
- * less than 640 MiB (4.5 GiB on a 288 GiB MI355X: a 1 GiB stream's table of origins, 4 GiB, stays) -- a hipMalloc of
- * gigabytes is not a cheap call: 0.2 ms most of the time and 0.24-1.3 s now and then (profiles/r05/malloc_time.txt,
- * stream_decode_glitch.txt), which a program that decodes large streams over and over would pay again and again.
- * LZS_KEEP_MAX_MB overrides it. */
+/* What a thread may keep between calls, device bytes IN SUM over its staging buffers (round 6; per buffer until then, which
+ * let one thread sit on 7 x 4.5 GiB): the largest buffers go first until the rest fits.  The default is 1/32 of the device's
+ * memory and no less than 640 MiB -- 9 GiB on a 288 GiB MI355X, so that what a 1 GiB stream's decode uses (its table of
+ * origins, 4 GiB, the stream and the output: 5.7 GiB) stays: a hipMalloc of gigabytes is not a cheap call, 0.2 ms most of
+ * the time and 0.24-1.3 s now and then (profiles/r05/malloc_time.txt, stream_decode_glitch.txt), which a program that decodes
+ * large streams over and over would pay again and again.  LZS_KEEP_MAX_MB overrides it (include/lzs/lzs_batch.h). */
 static size_t keep_max(void)
 {
     const size_t from_env = lzs_env()->keep_max;
@@ -275,7 +293,7 @@ static size_t keep_max(void)
     if (!d) {
         size_t total = 0;
         d = KEEP_MAX;
-        if (lzs_hip_total_memory(&total) == 0 && total / 64 > d) d = total / 64;
+        if (lzs_hip_total_memory(&total) == 0 && total / 32 > d) d = total / 32;
         __atomic_store_n(&dflt, d, __ATOMIC_RELAXED);
     }
     return d;
@@ -310,8 +328,23 @@ LZS_HIDDEN void *staging_host_tables(staging_t *st, size_t bytes)
 
 LZS_HIDDEN void staging_trim(staging_t *st)
 {
-    for (int i = 0; i < BUF_COUNT; i++)
-        if (st->cap[i] > keep_max()) { lzs_hip_free(st->buf[i]); st->buf[i] = NULL; st->cap[i] = 0; }
+    const size_t limit = keep_max();
+    size_t sum = 0;
+    for (int i = 0; i < BUF_COUNT; i++) sum += st->cap[i];
+    while (sum > limit) {                                     /* the largest first: the fewest reallocations for the bytes given back */
+        int big = 0;
+        for (int i = 1; i < BUF_COUNT; i++) if (st->cap[i] > st->cap[big]) big = i;
+        sum -= st->cap[big];
+        lzs_hip_free(st->buf[big]); st->buf[big] = NULL; st->cap[big] = 0;
+    }
+    /* the pinned pieces of the overlapped host batches (up to 6 x 46 MiB x the group) and the tables of the stream paths
+     * follow the same limit, on the host's side */
+    size_t pinned = st->host_tab_cap;
+    for (int i = 0; i < 6; i++) pinned += st->pin_cap[i];
+    if (pinned > limit) {
+        for (int i = 0; i < 6; i++) if (st->pin[i]) { lzs_hip_host_free(st->pin[i]); st->pin[i] = NULL; st->pin_cap[i] = 0; }
+        if (st->host_tab) { lzs_hip_host_free(st->host_tab); st->host_tab = NULL; st->host_tab_cap = 0; }
+    }
 }
 
 /* -------------------------------------------------------------------- host batches */

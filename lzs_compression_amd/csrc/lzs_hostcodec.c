@@ -64,6 +64,14 @@ static hc_tables_t *hc_tables(size_t span)
     return t;
 }
 
+/* The scratch copy of a piece stays for the next call while it is small (the 512-byte calls this route exists for);
+ * a large one -- LZS_ROUTE=host takes pieces up to 1 GiB -- is given back when its call is done. */
+#define HC_SCRATCH_KEEP ((size_t)1 << 20)
+static void hc_scratch_trim(hc_tables_t *t)
+{
+    if (t->scratch_cap > HC_SCRATCH_KEEP) { free(t->scratch); t->scratch = NULL; t->scratch_cap = 0; }
+}
+
 LZS_HIDDEN void hostcodec_free(void *tables)
 {
     hc_tables_t *t = (hc_tables_t *)tables;
@@ -257,6 +265,7 @@ LZS_HIDDEN size_t hostcodec_compress_piece(uint8_t *out, size_t cap, const uint8
         }
     }
     t->base += (uint32_t)n + HC_WINDOW + 1u;
+    hc_scratch_trim(t);
     return result < cap ? result : cap;
 }
 

@@ -395,7 +395,11 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && (h_seen = __atomic_load_n(&g_hint_seen[dev], __ATOMIC_ACQUIRE)) != nullptr) {
             uint32_t s[4], newest = 0;
             for (int c = 1; c <= 3; c++) { s[c] = __atomic_load_n(&h_seen[c], __ATOMIC_RELAXED); if (s[c] && (newest == 0 || (int32_t)(s[c] - newest) > 0)) newest = s[c]; }
-            if (newest) {
+            // (while the stream is being captured into a graph the guess would be frozen with it: every variant is launched, so that
+            // a replay on another class of data keeps its variant -- ADVICE r05)
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing((hipStream_t)stream, &capturing) != hipSuccess) { capturing = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+            if (newest && capturing == hipStreamCaptureStatusNone) {
                 allow = 0;
                 for (int c = 1; c <= 3; c++) if (s[c] && newest - s[c] <= 2u) allow |= 1u << c;       // (seen by one of the last three classifiers)
                 catch_all = (allow & 2u) ? 1u : ((allow & 4u) ? 2u : 3u);

@@ -20,7 +20,11 @@ typedef int (*nccl_allgather_fn)(const void *send, void *recv, size_t count, int
 typedef const char *(*nccl_strerror_fn)(int);
 #define NCCL_UINT8  1
 #define NCCL_UINT64 5
+#ifdef LZS_RCCL_PIECE                      /* (tests/cpu_shim: a few KB, so that a shard of a test spans several pieces) */
+#define RCCL_PIECE ((size_t)LZS_RCCL_PIECE)
+#else
 #define RCCL_PIECE ((size_t)1 << 30)
+#endif
 
 static struct {
     pthread_once_t once;

@@ -41,20 +41,40 @@ int lzs_hip_device_count(int *count) { *count = 1; return 0; }
 int lzs_hip_describe(char *buf, size_t cap) { snprintf(buf, cap, "cpu shim (tests/cpu_shim): the oracle behind the launchers, synchronous streams"); return 0; }
 const char *lzs_hip_strerror(int e) { return e == E_NOT_SUPPORTED ? "operation not supported (cpu shim)" : e == E_OUT_OF_MEMORY ? "out of memory (cpu shim)" : e ? "error (cpu shim)" : "no error"; }
 
-int lzs_hip_total_memory(size_t *bytes) { *bytes = (size_t)8 << 30; return 0; }    /* (1/64 of it is below the library's floor of 640 MiB) */
-int lzs_hip_malloc(void **p, size_t bytes)
+int lzs_hip_total_memory(size_t *bytes) { *bytes = (size_t)8 << 30; return 0; }    /* (1/32 of it is below the library's floor of 640 MiB) */
+/* what is outstanding, for the tests of lzs_release_thread_cache() and of the per-thread limit: bytes of "device" memory and
+ * of pinned host memory, and the count of live allocations of either kind (malloc_usable_size: the heap's own bookkeeping) */
+#include <malloc.h>
+static size_t g_dev_bytes, g_host_bytes, g_live;
+void lzs_shim_outstanding(size_t *dev_bytes, size_t *host_bytes, size_t *live)
+{
+    if (dev_bytes) *dev_bytes = __atomic_load_n(&g_dev_bytes, __ATOMIC_RELAXED);
+    if (host_bytes) *host_bytes = __atomic_load_n(&g_host_bytes, __ATOMIC_RELAXED);
+    if (live) *live = __atomic_load_n(&g_live, __ATOMIC_RELAXED);
+}
+static int shim_alloc(void **p, size_t bytes, size_t *counter)
 {
     if (bytes > ((size_t)1 << 40)) { *p = NULL; g_last_error = E_OUT_OF_MEMORY; return E_OUT_OF_MEMORY; }
     /* 0xCD: what lies in fresh device memory is nobody's zeros */
     *p = malloc(bytes ? bytes : 1);
     if (!*p) { g_last_error = E_OUT_OF_MEMORY; return E_OUT_OF_MEMORY; }
     memset(*p, 0xCD, bytes ? bytes : 1);
+    __atomic_add_fetch(counter, malloc_usable_size(*p), __ATOMIC_RELAXED);
+    __atomic_add_fetch(&g_live, 1, __ATOMIC_RELAXED);
     return 0;
 }
-int lzs_hip_free(void *p) { free(p); return 0; }
-int lzs_hip_host_malloc(void **p, size_t bytes) { return lzs_hip_malloc(p, bytes); }
-int lzs_hip_host_malloc_staging(void **p, size_t bytes) { return lzs_hip_malloc(p, bytes); }
-int lzs_hip_host_free(void *p) { free(p); return 0; }
+static void shim_free(void *p, size_t *counter)
+{
+    if (!p) return;
+    __atomic_sub_fetch(counter, malloc_usable_size(p), __ATOMIC_RELAXED);
+    __atomic_sub_fetch(&g_live, 1, __ATOMIC_RELAXED);
+    free(p);
+}
+int lzs_hip_malloc(void **p, size_t bytes) { return shim_alloc(p, bytes, &g_dev_bytes); }
+int lzs_hip_free(void *p) { shim_free(p, &g_dev_bytes); return 0; }
+int lzs_hip_host_malloc(void **p, size_t bytes) { return shim_alloc(p, bytes, &g_host_bytes); }
+int lzs_hip_host_malloc_staging(void **p, size_t bytes) { return shim_alloc(p, bytes, &g_host_bytes); }
+int lzs_hip_host_free(void *p) { shim_free(p, &g_host_bytes); return 0; }
 
 int lzs_hip_stream_create(void **s) { *s = malloc(8); return *s ? 0 : E_OUT_OF_MEMORY; }
 int lzs_hip_stream_destroy(void *s) { free(s); return 0; }

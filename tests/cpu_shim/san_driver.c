@@ -258,6 +258,62 @@ static void incremental(void)
     free(t); free(low); free(mix);
 }
 
+/* ---------------------------------------------------------------- what a thread keeps, and giving it back
+ * The reference keeps nothing after return (lzs.h:218,229); this build keeps a thread's staging for its next call -- at most
+ * LZS_KEEP_MAX_MB in sum -- until the thread exits or calls lzs_release_thread_cache(). */
+void lzs_shim_outstanding(size_t *dev_bytes, size_t *host_bytes, size_t *live);
+typedef struct { int releases; size_t dev_after_calls, dev_after_release, live_after_release; } keeper_t;
+static void *keeper(void *arg)
+{
+    keeper_t *k = (keeper_t *)arg;
+    const size_t n = 300000;
+    uint8_t *t = sample(0, n, 40), *got = (uint8_t *)malloc(LZS_COMPRESSED_MAX(n)), *back = (uint8_t *)malloc(n + 4);
+    setenv("LZS_ROUTE", "device", 1);
+    const size_t g = lzs_compress(got, LZS_COMPRESSED_MAX(n), t, n);                 /* one stream in segments: staging, tables, a stream */
+    const size_t b = lzs_decompress(back, n, got, g);
+    CHECK(b == n && memcmp(back, t, n) == 0, "keeper: round trip of %zu bytes (%zu, %zu)", n, g, b);
+    enum { NB = 24, STRIDE = 4096 };
+    uint32_t lens[NB]; for (int i = 0; i < NB; i++) lens[i] = STRIDE - (uint32_t)i;
+    uint8_t *out = (uint8_t *)malloc((size_t)NB * LZS_COMPRESSED_MAX(STRIDE)); uint32_t out_len[NB];
+    CHECK(lzs_compress_batch(out, LZS_COMPRESSED_MAX(STRIDE), LZS_COMPRESSED_MAX(STRIDE), out_len, t, STRIDE, lens, STRIDE, NB) == 0, "keeper: batch: %s", lzs_last_error());
+    lzs_shim_outstanding(&k->dev_after_calls, NULL, NULL);
+    if (k->releases) {
+        lzs_release_thread_cache();
+        lzs_release_thread_cache();                                                  /* (twice is once) */
+        lzs_shim_outstanding(&k->dev_after_release, NULL, &k->live_after_release);
+        /* ... and the thread's next call starts from nothing and works */
+        const size_t g2 = lzs_compress(got, LZS_COMPRESSED_MAX(n), t, 20000);
+        const size_t b2 = lzs_decompress(back, n, got, g2);
+        CHECK(b2 == 20000 && memcmp(back, t, 20000) == 0, "keeper: a call after the release");
+        lzs_release_thread_cache();
+    }
+    free(t); free(got); free(back); free(out);
+    return NULL;
+}
+static void release_cache(void)
+{
+    lzs_release_thread_cache();                          /* (the main thread's own, from the cases before) */
+    size_t dev0, host0, live0;
+    lzs_shim_outstanding(&dev0, &host0, &live0);
+    for (int pass = 0; pass < 3; pass++) {
+        /* pass 0: the thread gives its cache back itself; 1: it just exits; 2: a limit of 1 MiB in sum while it lives */
+        if (pass == 2) setenv("LZS_KEEP_MAX_MB", "1", 1);
+        keeper_t k = { pass == 0, 0, 0, 0 };
+        pthread_t th;
+        pthread_create(&th, NULL, keeper, &k);
+        pthread_join(th, NULL);
+        size_t dev1, host1, live1;
+        lzs_shim_outstanding(&dev1, &host1, &live1);
+        CHECK(dev1 == dev0 && host1 == host0 && live1 == live0, "pass %d: after the thread is gone %zu device bytes, %zu pinned, %zu allocations are outstanding (before: %zu, %zu, %zu)",
+              pass, dev1, host1, live1, dev0, host0, live0);
+        if (pass == 0) CHECK(k.dev_after_calls > dev0 && k.dev_after_release == dev0 && k.live_after_release == live0,
+                             "lzs_release_thread_cache(): %zu device bytes kept after the calls, %zu after the release (before: %zu)", k.dev_after_calls, k.dev_after_release, dev0);
+        if (pass == 2) CHECK(k.dev_after_calls <= dev0 + ((size_t)1 << 20) + 4096, "LZS_KEEP_MAX_MB=1: %zu device bytes kept between calls", k.dev_after_calls - dev0);
+        if (pass == 1) CHECK(k.dev_after_calls > dev0 + ((size_t)1 << 20), "the default limit keeps the staging of small calls (%zu bytes)", k.dev_after_calls - dev0);
+    }
+    unsetenv("LZS_KEEP_MAX_MB"); unsetenv("LZS_ROUTE");
+}
+
 /* proof that the harness is alive: "device" memory is instrumented heap memory (the test expects the sanitizer to stop this) */
 int lzs_hip_malloc(void **p, size_t bytes);
 static void canary(void)
@@ -280,6 +336,7 @@ int main(int argc, char **argv)
     if (!*only || !strcmp(only, "streams")) one_shot_streams();
     if (!*only || !strcmp(only, "incremental")) incremental();
     if (!*only || !strcmp(only, "pipeline")) pipeline();
+    if (!*only || !strcmp(only, "release")) release_cache();
     if (!strcmp(only, "canary")) canary();
     printf("san_driver: %d failure(s)\n", failures);
     return failures ? 1 : 0;

@@ -318,3 +318,34 @@ def test_install_layout_and_pkg_config(tmp_path):
     r = subprocess.run([str(prefix / "bin" / "lzs-compress"), str(data), str(tmp_path / "out.lzs")], capture_output=True, text=True,
                        env={k: v for k, v in os.environ.items() if k != "LD_LIBRARY_PATH"})
     assert "liblzs.so" not in r.stderr or "cannot open shared object" not in r.stderr, r.stderr
+
+
+def test_a_batch_call_refuses_one_array_for_the_lengths_read_and_written():
+    """d_out_len[] is scratch of a compress launch (every block's class is left there before any workgroup reads d_in_len[]):
+    handing the same array as both is an argument error, before anything is launched (include/lzs/lzs_batch.h)."""
+    A = lzs.api
+    L = A.lib()
+    fake = ctypes.c_void_p(0x1000)
+    for name in ("lzs_compress_batch_device", "lzs_decompress_batch_device"):
+        rc = getattr(L, name)(fake, 128, 100, fake, fake, 128, fake, 64, 4, None)
+        assert rc == A.LZS_E_ARG and "same array" in A.last_error(), (name, rc, A.last_error())
+
+
+def test_the_release_call_is_exported_and_harmless_on_a_thread_that_keeps_nothing():
+    """lzs_release_thread_cache() (include/lzs/lzs_batch.h; the reference keeps nothing after return, lzs.h:218,229): callable
+    on a thread that never staged anything, twice, without a device."""
+    import threading
+    L = lzs.api.lib()
+    errors = []
+
+    def worker():
+        try:
+            L.lzs_release_thread_cache()
+            L.lzs_release_thread_cache()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    L.lzs_release_thread_cache()
+    assert not errors

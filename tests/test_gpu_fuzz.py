@@ -3,11 +3,12 @@ one-shot calls with random segment sizes, cut capacities, truncated and garbage 
 concatenated streams, the incremental interface in random pieces, device stream calls at odd
 alignments, ragged batches -- against the oracle and, where it was built, the compiled reference).
 
-The seed list starts with every seed that ever failed during development (DESIGN.md section 7 says
-which commit fixed which) and goes on with fresh ones until the time is up."""
+The seed list is FIXED: every seed that ever failed during development (DESIGN.md section 7 says which commit fixed
+which) and 600 pinned ones -- the gate's verdict is a function of the tree, not of the clock or the box (VERDICT r05:
+rounds 1-5 ran fresh seeds for a minute here).  Fresh seeds are `python tests/dev/fuzz_all.py SECONDS SEED0`, whose
+runs are kept under profiles/rNN/fuzz_*.txt."""
 import importlib.util
 import os
-import time
 
 import pytest
 
@@ -21,19 +22,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REGRESSION_SEEDS = [100067, 100358, 500000, 700000, 702200]
 
 
-def test_fuzz_regression_seeds_then_fresh_ones_for_a_minute():
+# 2 000 000 ...: the range whose seeds take the four routes of the small calls in turn (device, by size, host, device)
+PINNED_SEEDS = list(range(2_000_000, 2_000_600))
+
+
+def test_fuzz_regression_seeds_and_six_hundred_pinned_ones():
     if not torch.cuda.is_available():
         pytest.fail("these tests need a GPU (no fallback exists)")
     spec = importlib.util.spec_from_file_location("fuzz_all", os.path.join(HERE, "dev", "fuzz_all.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    t0, done = time.time(), 0
-    for seed in REGRESSION_SEEDS:
+    for seed in REGRESSION_SEEDS + PINNED_SEEDS:
         fz.check_seed(seed)
-        done += 1
-    seed = 2_000_000
-    while time.time() - t0 < 60.0:
-        fz.check_seed(seed)
-        seed += 1
-        done += 1
-    assert done >= len(REGRESSION_SEEDS)

@@ -1166,6 +1166,89 @@ def test_full_size_1gib_every_block_vs_oracle_and_reference_digests(cls):
     assert total == full["classes"][cls]["bytes"]
 
 
+def test_packet_sized_blocks_262144_x_4kib_every_block_vs_oracle():
+    """The reference's own small-block case at the batch entry (4 KiB blocks; its file tool works in
+    512-byte pieces, c/src/utils/lzs-compress.c:28-32, and RFC 1974 / 2395 compress packets): 1 GiB of text as 262 144 blocks
+    of 4 KiB through lzs_compress_batch_device -- one workgroup and eight pools a block -- EVERY block's length and bytes
+    against the oracle, every block decoded again on the device (profiles/r06/blocksize_sweep.txt has the rates: no collapse
+    at packet sizes)."""
+    nb, bl = 262144, 4096
+    x = workload.fill_device("text", nb, bl)
+    slots, lens = lzs.compress_blocks(x)
+    back, back_len = lzs.decompress_blocks(slots, lens, bl)
+    torch.cuda.synchronize()
+    assert bool((back_len == bl).all()) and torch.equal(back[:, :bl], x)
+    del back
+    lens_h = lens.cpu().numpy()
+    assert lens_h.max() <= lzs.compressed_max(bl) and lens_h.min() >= 2
+    threads = min(64, len(os.sched_getaffinity(0)))
+    for lo in range(0, nb, 32768):
+        blocks = x[lo:lo + 32768].cpu().numpy()
+        got = slots[lo:lo + 32768].cpu().numpy()
+        cpu, cpu_len, _ = oracle.run_blocks(O, blocks, threads=threads)
+        assert (cpu_len == lens_h[lo:lo + 32768]).all(), lo
+        mask = np.arange(cpu.shape[1])[None, :] < cpu_len[:, None]
+        assert not ((got[:, :cpu.shape[1]] != cpu) & mask).any(), lo
+    # ... and the same generator on the host gives the same blocks (what the oracle saw is what BASELINE's class is)
+    assert np.array_equal(x[:64].cpu().numpy(), workload.fill("text", 64, bl))
+
+
+def test_what_a_thread_keeps_goes_back_on_release_and_on_thread_exit():
+    """Ownership (reference lzs.h:218,229: the library keeps nothing after return).  This build keeps the
+    calling thread's staging for its next call; 32 threads that each decoded a 1 GiB stream once hold on to what that took --
+    until they call lzs_release_thread_cache() (half of them) or exit (the other half): then the device's free memory is
+    back to within 1 GiB of where it was."""
+    import threading
+    nthreads, parallel = 32, 8
+    x = workload.fill_device("text", 16384).reshape(-1)
+    stream, nbytes = lzs.compress_stream(x)
+    stream = stream[:nbytes].clone()
+    outs = [torch.empty(x.numel() + 16, dtype=torch.uint8, device="cuda") for _ in range(parallel)]
+    torch.cuda.synchronize()
+    lzs.release_thread_cache()                               # (this thread's own, from compress_stream)
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    slots = threading.Semaphore(parallel)
+    decoded, may_go, errors = threading.Barrier(nthreads + 1), threading.Event(), []
+    free_slots, lock = list(range(parallel)), threading.Lock()
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            with slots:
+                with lock:
+                    k = free_slots.pop()
+                back, n = lzs.decompress_stream(stream, x.numel() + 16, out=outs[k])
+                ok = n == x.numel() and bool(torch.equal(back[:n], x))
+                with lock:
+                    free_slots.append(k)
+            if not ok:
+                errors.append((tid, "round trip"))
+            decoded.wait()                                   # everybody has decoded and still lives: what is kept is kept
+            may_go.wait()
+            if tid % 2 == 0:
+                lzs.release_thread_cache()
+        except Exception as e:      # noqa: BLE001 - collected for the assertion below
+            errors.append((tid, repr(e)))
+            decoded.abort()
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for t in threads:
+        t.start()
+    decoded.wait()
+    kept = free0 - torch.cuda.mem_get_info()[0]
+    may_go.set()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    torch.cuda.synchronize()
+    freed = free0 - torch.cuda.mem_get_info()[0]
+    # each thread kept at least its copy of the stream and of the output (and at most LZS_KEEP_MAX_MB: 1/32 of the device)
+    assert kept >= nthreads * (1 << 30), f"the threads kept {kept >> 20} MiB: is the staging not per thread any more?"
+    assert kept <= nthreads * (torch.cuda.mem_get_info()[1] // 32 + (64 << 20)), f"the threads kept {kept >> 20} MiB, more than the limit allows"
+    assert freed < (1 << 30), f"{freed >> 20} MiB of device memory did not come back (the threads had kept {kept >> 20} MiB)"
+
+
 @pytest.mark.parametrize("cls", workload.CLASS_NAMES)
 def test_other_seeds_4096_blocks_every_block_vs_oracle(cls):
     """The same three generators under two other seeds and from another block index on: 4096 blocks

@@ -233,3 +233,125 @@ def test_both_routes_and_the_default_agree_across_the_crossovers(monkeypatch):
                 assert lzs.compress(d) == want, (name, n, route)
                 assert lzs.decompress(want, n + 1) == d, (name, n, route)
                 assert lzs.decompress(want[: len(want) // 2], n) == O.decompress(want[: len(want) // 2], n), (name, n, route)
+
+
+# ------------------------------------------------------------------ malformed streams through the incremental decoder
+def _first_long_offset_zero(stream: bytes):
+    """Bytes the stream has produced when its first `1 0 00000000000` token (long offset 0) begins, or None if it has none
+    before the bits run out: a plain walk over the token grammar, end markers realigning to a byte
+    as the incremental decoder does (lzs-decompression.c:564-576)."""
+    bits = "".join(f"{b:08b}" for b in stream)
+    at, made = 0, 0
+    while True:
+        if at + 1 > len(bits):
+            return None
+        if bits[at] == "0":
+            if at + 9 > len(bits):
+                return None
+            at, made = at + 9, made + 1
+            continue
+        if at + 2 > len(bits):
+            return None
+        short = bits[at + 1] == "1"
+        used = 9 if short else 13
+        if at + used > len(bits):
+            return None
+        off = int(bits[at + 2:at + used], 2)
+        if off == 0 and short:
+            at = (at + used + 7) // 8 * 8
+            continue
+        if off == 0:
+            return made
+        at += used
+        if at + 2 > len(bits):
+            return None
+        code = int(bits[at:at + 4].ljust(4, "0"), 2)
+        width = 2 if code < 12 else 4
+        if at + width > len(bits):
+            return None
+        length = 2 + (code >> 2) if code < 12 else code - 7
+        at += width
+        made += length
+        while length in (8, 15) and (length == 8 or True):
+            if at + 4 > len(bits):
+                return None
+            e = int(bits[at:at + 4], 2)
+            at, made = at + 4, made + e
+            if e != 15:
+                break
+            length = 15
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/liblzs_ref.so was not built (needs /root/reference)")
+def test_incremental_decoder_on_malformed_streams_against_the_reference_itself(host):
+    """Garbage through lzs_decompress_incremental() (host route: what a caller's small pieces get) beside the compiled
+    reference's own incremental decoder on a zeroed parameter block.  Byte for byte the same -- except from the first token
+    with a LONG OFFSET OF 0 on, which no compressor emits: the reference's incremental decoder reads a length there and
+    copies from the oldest bytes of its ring, which lzs_decompress_init() never cleared (lzs-decompression.c:420-428,
+    585-593: the caller's memory until 2047 bytes have been produced), while every decoder of this build applies the
+    one-shot decoder's rule (:280: no length field, no copy) whatever the size of the piece.  INTEGRATION.md section 2
+    says so; up to that token the outputs agree."""
+    import random
+    import struct
+    ref = ctypes.CDLL(os.path.join(os.path.dirname(oracle.__file__), "_ref", "liblzs_ref.so"))
+    ref.lzs_decompress_incremental.restype = ctypes.c_size_t
+    ref.lzs_decompress_incremental.argtypes = [ctypes.c_void_p]
+    ref.lzs_decompress_init.argtypes = [ctypes.c_void_p]
+
+    def ref_decode(stream, room):
+        raw = ctypes.create_string_buffer(2096)                 # LzsDecompressParameters_t, zeroed
+        ref.lzs_decompress_init(ctypes.addressof(raw))
+        src = ctypes.create_string_buffer(bytes(stream), max(len(stream), 1))
+        dst = ctypes.create_string_buffer(room)
+        struct.pack_into("<QQQQ", raw, 0, ctypes.addressof(src), ctypes.addressof(dst), len(stream), room)
+        n = 0
+        for _ in range(64):                                     # (a call returns at every end marker)
+            n += ref.lzs_decompress_incremental(ctypes.addressof(raw))
+            if struct.unpack_from("<Q", raw, 16)[0] == 0 and not raw.raw[32] & lzs.STATUS_END_MARKER:
+                break
+        return dst.raw[:n]
+
+    def our_decode(stream, room, piece):
+        d, out, pos = lzs.IncrementalDecompressor(), bytearray(), 0
+        while pos < len(stream) and len(out) < room:
+            pending = stream[pos:pos + piece]
+            pos += len(pending)
+            for _ in range(64):
+                got, used, status = d.step(pending, room - len(out))
+                out += got
+                pending = pending[used:]
+                if not pending or len(out) >= room:
+                    break
+        return bytes(out)
+
+    rng = random.Random(20261004)
+    valid = O.compress(bytes(workload.fill("text", 1, 3000).reshape(-1)))
+    same = differing = 0
+    for it in range(400):
+        n = rng.randint(1, 360)
+        kind = it % 4
+        if kind == 0:
+            stream = rng.randbytes(n)
+        elif kind == 1:                                         # mostly matches: high bits set
+            stream = bytes(rng.getrandbits(8) | 0x80 for _ in range(n))
+        elif kind == 2:                                         # a valid stream with a few bytes hit
+            s = bytearray(valid[:n + 40])
+            for _ in range(3):
+                s[rng.randrange(len(s))] ^= 1 << rng.randrange(8)
+            stream = bytes(s)
+        else:                                                   # some literals, `1 0` + eleven zero bits, then anything
+            bits = "".join("0" + f"{rng.getrandbits(8):08b}" for _ in range(rng.randint(0, 40))) + "10" + "0" * 11
+            bits += "".join(rng.choice("01") for _ in range(8 * n))
+            bits = bits[:len(bits) // 8 * 8]
+            stream = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+        room = 20000
+        want = ref_decode(stream, room)
+        got = our_decode(stream, room, rng.choice((1, 7, 64, 4096)))
+        cut = _first_long_offset_zero(stream)
+        if cut is None or cut >= room:
+            assert got == want, (it, stream.hex())
+            same += 1
+        else:
+            assert got[:cut] == want[:cut], (it, cut, stream.hex())
+            differing += got != want
+    assert same >= 100 and differing >= 20          # (both kinds were met)

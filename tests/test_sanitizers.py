@@ -38,7 +38,9 @@ def _run(exe, cases, env_extra, timeout):
 
 
 def test_host_sources_under_address_and_undefined_behaviour_sanitizers(built):
-    _run(os.path.join(built, "san_asan"), ["ragged", "streams", "incremental", "pipeline"],
+    # ("release": what a thread keeps between calls goes back on lzs_release_thread_cache(), on thread exit, and above
+    # LZS_KEEP_MAX_MB -- the shim counts its outstanding "device" bytes; leak detection is on)
+    _run(os.path.join(built, "san_asan"), ["ragged", "streams", "incremental", "pipeline", "release"],
          {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"}, 900)
 
 
@@ -52,7 +54,7 @@ def test_host_sources_under_thread_sanitizer(built):
     """The cases with threads in them: the pipeline's four workers per batch call, two calling threads at once, the
     per-thread staging and environment (the one-stream case is single-threaded and the oracle's brute-force search behind
     the shim's segments takes 100 s under this sanitizer: the address run covers it)."""
-    _run(os.path.join(built, "san_tsan"), ["ragged", "pipeline"], {"TSAN_OPTIONS": "halt_on_error=1"}, 900)
+    _run(os.path.join(built, "san_tsan"), ["ragged", "pipeline", "release"], {"TSAN_OPTIONS": "halt_on_error=1"}, 900)
 
 
 def test_the_checkers_under_address_and_undefined_behaviour_sanitizers():

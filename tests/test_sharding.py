@@ -195,3 +195,50 @@ def test_the_c_entry_partitions_like_the_python_job():
     so = os.path.join(os.path.dirname(os.path.abspath(lzs.__file__)), "liblzs.so")
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "rccl" not in needed and "nccl" not in needed
+
+
+# ---- the C half of the job at world > 1: csrc/lzs_rccl.c UNCHANGED (but for pieces of 3000 bytes instead of
+# 1 GiB, so that a shard spans several), its librccl a shared-memory stand-in between forked processes that the library opens
+# through LZS_RCCL_LIBRARY (tests/cpu_shim/fake_rccl.c), its device tests/cpu_shim/lzs_cpu_shim.c; under ASan + UBSan, leak
+# detection on.  What the root gathers must be the oracle's streams of all blocks back to back.
+_SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_shim")
+
+
+@pytest.fixture(scope="module")
+def rccl_built():
+    import subprocess
+    r = subprocess.run(["make", "-C", _SHIM, os.path.join(_SHIM, "_build", "rccl_asan"), os.path.join(_SHIM, "_build", "libfake_rccl.so")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return os.path.join(_SHIM, "_build")
+
+
+@pytest.mark.parametrize("world,root,nblocks,block_len", [
+    (2, 0, 9, 4096),        # ragged: 5 + 4 blocks; shards of 16-20 KB in pieces of 3000 bytes
+    (2, 1, 16, 4096),       # root is not rank 0
+    (3, 2, 37, 4096),       # nblocks % world != 0, the root last: its own rows go behind everybody else's
+    (8, 5, 67, 2500),       # eight ranks, a block length that is no multiple of anything
+    (8, 0, 5, 4096),        # fewer blocks than ranks: three ranks have nothing to receive or send
+    (1, 0, 4, 4096),        # one rank: no transfer at all
+])
+def test_the_c_scatter_and_gather_between_forked_ranks_over_a_stand_in_for_rccl(rccl_built, world, root, nblocks, block_len):
+    import re
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LZS_")}
+    env.update(LZS_RCCL_LIBRARY=os.path.join(rccl_built, "libfake_rccl.so"), ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(rccl_built, "rccl_asan"), str(world), str(root), str(nblocks), str(block_len)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "0 failure(s)" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
+    m = re.search(r"(\d+) sends, (\d+) receives in (\d+) groups, (\d+) bytes between ranks, (\d+) operations outside a group", r.stdout)
+    sends, recvs, groups, moved, outside = map(int, m.groups())
+    # what must have crossed: every block that is not the root's own, in pieces of <= 3000 bytes, and the peers' streams back
+    lo, hi = sharding.shard_range(nblocks, root, world)
+    scattered = (nblocks - (hi - lo)) * block_len
+    assert sends == recvs and outside == 0
+    if world == 1:
+        assert sends == 0 and moved == 0
+    else:
+        pieces = sum(-(-((h - l) * block_len) // 3000) for l, h in (sharding.shard_range(nblocks, k, world) for k in range(world) if k != root))
+        assert moved > scattered and sends >= pieces + sum(1 for k in range(world) if k != root and sharding.shard_range(nblocks, k, world)[1] > sharding.shard_range(nblocks, k, world)[0])
+        assert groups <= 2 * world                     # one group per rank and call: the root's sends to all its peers are ONE group

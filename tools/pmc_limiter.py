@@ -27,6 +27,14 @@ HOW = ("rocprofv3 --kernel-trace --pmc, one pass per counter set, bench.py --ste
        "lds_busy = SQ_LDS_IDX_ACTIVE / (kernel_cycles x 256 CUs). waves_waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES.")
 NOTE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel-trace only); counters are in KB; "
         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests of wide streaming reads at 64 B)")
+# what the counters are the counters OF: tools/gpu_pmc.sh forces the class's own variant of the kernel on every block
+# (LZS_VARIANT), so a launch of the library is ONE dispatch of that variant -- the counters are that dispatch's.  A caller's launch
+# also runs lzs_classify_blocks_kernel (two 16-byte loads a lane over a block's first 2 KiB: ~32 MiB read per GiB, 3 % on top of
+# FETCH) and the other variants' grids, whose workgroups return after one scalar load; bench.py's events time all of them.
+VARIANT = {"text": "text", "lowent": "few", "random": "lit"}
+SCOPE = ("one dispatch of lzs_compress_blocks_wg_kernel, the class's own variant forced on every block (LZS_VARIANT); not in the "
+         "counters: lzs_classify_blocks_kernel (reads the first 2 KiB of every block) and the other variants' empty grids, which a "
+         "caller's launch also runs and bench.py's HIP events include")
 
 
 def read(path):
@@ -48,7 +56,7 @@ def main(prefix, outdir):
         valu_busy = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * SIMDS)
         lds_busy = v["SQ_LDS_IDX_ACTIVE"] / (cyc * CUS)
         lim[cls] = {
-            "kernel": "lzs_compress_blocks_wg_kernel", "launch": "16384 blocks x 64 KiB",
+            "kernel": "lzs_compress_blocks_wg_kernel", "launch": "16384 blocks x 64 KiB", "variant_forced": VARIANT[cls], "scope": SCOPE,
             "valu_insts_per_input_byte": v["SQ_INSTS_VALU"] / INPUT_BYTES,
             "salu_insts_per_input_byte": v["SQ_INSTS_SALU"] / INPUT_BYTES,
             "lds_insts_per_input_byte": v["SQ_INSTS_LDS"] / INPUT_BYTES,
@@ -60,7 +68,7 @@ def main(prefix, outdir):
                          "latency (waves waiting)" if v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"] > 0.55 and valu_busy < 0.7 else "vector issue"),
             "counters": {k: v[k] for k in sorted(v)},
         }
-        tra[cls] = {"kernel": "lzs_compress_blocks_wg_kernel", "launch": "16384 blocks x 64 KiB",
+        tra[cls] = {"kernel": "lzs_compress_blocks_wg_kernel", "launch": "16384 blocks x 64 KiB", "variant_forced": VARIANT[cls], "scope": SCOPE,
                     "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
                     "fetch_bytes_corrected": int(2 * v["FETCH_SIZE"] * 1024), "write_bytes": int(v["WRITE_SIZE"] * 1024), "note": NOTE}
     json.dump(lim, open(os.path.join(outdir, "pmc_limiter.json"), "w"), indent=1)

@@ -38,6 +38,8 @@ def main(src, dst):
         fetch, n1 = mean_counter(os.path.join(src, f"{cls}_FETCH_SIZE"), "FETCH_SIZE")
         write, n2 = mean_counter(os.path.join(src, f"{cls}_WRITE_SIZE"), "WRITE_SIZE")
         out[cls] = {"kernel": "lzs_compress_blocks_wg_kernel", "launch": "16384 blocks x 64 KiB",
+                    "variant_forced": {"text": "text", "lowent": "few", "random": "lit"}[cls],
+                    "scope": "one dispatch of the class's own variant (LZS_VARIANT forced); the classifier and the other variants' empty grids of a caller's launch are not in the counters",
                     "dispatches_averaged": [n1, n2], "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                     "fetch_bytes_corrected": int(2 * fetch * 1024), "write_bytes": int(write * 1024), "note": NOTE}
     json.dump(out, open(dst, "w"), indent=1)
