@@ -58,14 +58,11 @@ namespace wgv_text {
 #define LZS_WGV_PRIO 1
 // (six workgroups per CU for THIS variant cost more in buckets than the sixth workgroup gives: 1024 / 512 buckets 72.6 GB/s,
 // 896 / 512 71.5, 1152 / 256 70.3, 768 / 1024 69.0 against 74.7 -- profiles/r05/ab_s41)
-#ifdef LZS_EXP_TEXT_POOL     // (tools/probes/ab.sh experiments on the default variant's shape: round 6's pool of 256, its bucket count,
-#define LZS_WGV_POOL LZS_EXP_TEXT_POOL   // SEARCH's constants as literals)
+#ifdef LZS_EXP_TEXT_POOL     // (tools/probes/ab.sh: round 6's pool of 256 and its bucket counts, profiles/r06/ab_s3)
+#define LZS_WGV_POOL LZS_EXP_TEXT_POOL
 #endif
 #ifdef LZS_EXP_TEXT_HEAD3
 #define LZS_WGV_HEAD3 LZS_EXP_TEXT_HEAD3
-#endif
-#ifdef LZS_EXP_TEXT_LEAN
-#define LZS_WGV_LEAN 1
 #endif
 #include "kernels/compress_wg.inc"
 }
@@ -76,23 +73,28 @@ namespace wgv_safe {
 #include "kernels/compress_wg.inc"
 }
 #ifndef LZS_ONE_VARIANT      // (tools/probes/ab.sh -DLZS_ONE_VARIANT: the default alone, for the probes that launch it directly)
-namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- a sixth workgroup per CU; no priorities (+0.2 %: noise)
-#define LZS_WGV_HEAD3 768     // (PACK chunk by chunk: the one-pass form takes 81 vector registers, and the sixth wave per SIMD
-#define LZS_WGV_HEAD2 512     // is there up to 80; these blocks have few tokens to format anyway)
-#define LZS_WGV_PACK_BY_CHUNK 1
+// Round 6: NEITHER of the two keeps a 3-byte chain (LZS_WGV_NO3: every position walks the 2-byte chain with the full rule, which is
+// exact for any block -- that chain is complete for every match of 2 and more).  Where grams do not repeat the 3-byte chain holds
+// collisions only, where few grams repeat endlessly it holds what the 2-byte chain holds; without head3[] / link3[] HASH and CHAIN do
+// half the work, a step has no restart on another chain, and 22.6 KB of LDS and 70-72 vector registers are SEVEN workgroups per CU
+// with twice the 2-byte buckets.  profiles/r06/ab_s10 ... ab_s12: high entropy 107.4 -> 122.4 GB/s (1024 buckets 115, 2048 119-122, 4096
+// -- five workgroups -- 110; hops 0 / 1 / 2 / 3 / 4 / 5: 120.2 / 122.4 / 121.5 / 119.1 / 116.0 / 112.8; two sub-steps 112-116), low entropy
+// 416 -> 435 (512 / 1024 / 2048 buckets 433 / 436 / 437; one hop 419).  Forced on text they are 58-68 GB/s: the default keeps both chains.
+namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- seven workgroups per CU; no priorities (+0.2 %: noise)
+#define LZS_WGV_NO3 1
+#define LZS_WGV_HEAD2 2048
+#define LZS_WGV_PACK_BY_CHUNK 1   // (these blocks have few tokens to format, and the one-pass form takes 81 vector registers)
 #define LZS_WGV_LEAN 1
-#define LZS_WGV_HOPS 0
+#define LZS_WGV_HOPS 0        // (few candidates, long matches: the quick-reject test itself is the cost)
 #include "kernels/compress_wg.inc"
 }
-namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop, PACK chunk by chunk
+namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop with one hop in front, PACK chunk by chunk
+#define LZS_WGV_NO3 1
+#define LZS_WGV_HEAD2 2048
 #define LZS_WGV_SUBSTEPS 1
-#define LZS_WGV_HOPS 3
+#define LZS_WGV_HOPS 1
 #define LZS_WGV_PACK_BY_CHUNK 1
 #define LZS_WGV_PRIO 1
-#ifndef LZS_EXP_LIT6          // six workgroups per CU here too: the 3-byte chains of such blocks hold collisions whatever the table's
-#define LZS_EXP_LIT6 512      // size, and with 512 buckets (384 ... 544 measured alike, 576 is five workgroups again, 256 gives it
-#endif                        // back to collisions) the LDS is 26.7 KB: 99.3 -> 107.6 GB/s (profiles/r05/ab_s39, ab_s40)
-#define LZS_WGV_HEAD3 LZS_EXP_LIT6
 #define LZS_WGV_LEAN 1
 #include "kernels/compress_wg.inc"
 }
