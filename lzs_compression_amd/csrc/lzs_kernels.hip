@@ -76,23 +76,29 @@ namespace wgv_safe {
 // Round 6: NEITHER of the two keeps a 3-byte chain (LZS_WGV_NO3: every position walks the 2-byte chain with the full rule, which is
 // exact for any block -- that chain is complete for every match of 2 and more).  Where grams do not repeat the 3-byte chain holds
 // collisions only, where few grams repeat endlessly it holds what the 2-byte chain holds; without head3[] / link3[] HASH and CHAIN do
-// half the work, a step has no restart on another chain, and 22.6 KB of LDS and 70-72 vector registers are SEVEN workgroups per CU
-// with twice the 2-byte buckets.  profiles/r06/ab_s10 ... ab_s12: high entropy 107.4 -> 122.4 GB/s (1024 buckets 115, 2048 119-122, 4096
-// -- five workgroups -- 110; hops 0 / 1 / 2 / 3 / 4 / 5: 120.2 / 122.4 / 121.5 / 119.1 / 116.0 / 112.8; two sub-steps 112-116), low entropy
-// 416 -> 435 (512 / 1024 / 2048 buckets 433 / 436 / 437; one hop 419).  Forced on text they are 58-68 GB/s: the default keeps both chains.
-namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- seven workgroups per CU; no priorities (+0.2 %: noise)
+// half the work, a step has no restart on another chain, and 18.5 KB of LDS with the registers held to 64 (LZS_WGV_WAVES: no vector
+// spills) are EIGHT workgroups per CU -- all a SIMD takes.  profiles/r06/ab_s10 ... ab_s15, GB/s through the library's launch:
+//   high entropy 107.4 (both chains, six workgroups) -> 115 (no 3-byte chain, 1024 buckets, seven) -> 119-122 (2048 buckets; hops 0 / 1 / 2 /
+//   3 / 4 / 5: 120.2 / 122.4 / 121.5 / 119.1 / 116.0 / 112.8; 4096 buckets -- five workgroups -- 110; two sub-steps 112-116) -> 125.4 (eight
+//   workgroups with 1024 buckets, two hops; one 124.3, none 116.7)
+//   low entropy 416 -> 433 / 436 / 437 (512 / 1024 / 2048 buckets, seven workgroups; one hop 419) -> 493 (eight workgroups, 1024 buckets; 512:
+//   484; run mode's pool 64 / 256: 470 / 460, its rounds 1 / 3: 491 / 491)
+// Forced on text they are 58-68 GB/s: the default keeps both chains.
+namespace wgv_few {           // blocks of few distinct grams: long matches, the kernel waits -- eight workgroups per CU; no priorities (+0.2 %: noise)
 #define LZS_WGV_NO3 1
-#define LZS_WGV_HEAD2 2048
-#define LZS_WGV_PACK_BY_CHUNK 1   // (these blocks have few tokens to format, and the one-pass form takes 81 vector registers)
+#define LZS_WGV_HEAD2 1024
+#define LZS_WGV_WAVES 8
+#define LZS_WGV_PACK_BY_CHUNK 1   // (these blocks have few tokens to format)
 #define LZS_WGV_LEAN 1
 #define LZS_WGV_HOPS 0        // (few candidates, long matches: the quick-reject test itself is the cost)
 #include "kernels/compress_wg.inc"
 }
-namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop with one hop in front, PACK chunk by chunk
+namespace wgv_lit {           // blocks that are nearly all literals: one full step per pass of the SEARCH loop with two hops in front, PACK chunk by chunk
 #define LZS_WGV_NO3 1
-#define LZS_WGV_HEAD2 2048
+#define LZS_WGV_HEAD2 1024
+#define LZS_WGV_WAVES 8
 #define LZS_WGV_SUBSTEPS 1
-#define LZS_WGV_HOPS 1
+#define LZS_WGV_HOPS 2
 #define LZS_WGV_PACK_BY_CHUNK 1
 #define LZS_WGV_PRIO 1
 #define LZS_WGV_LEAN 1
