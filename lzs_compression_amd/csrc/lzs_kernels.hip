@@ -64,6 +64,18 @@ namespace wgv_text {
 #ifdef LZS_EXP_TEXT_HEAD3
 #define LZS_WGV_HEAD3 LZS_EXP_TEXT_HEAD3
 #endif
+#ifdef LZS_EXP_TEXT_WAVES
+#define LZS_WGV_WAVES LZS_EXP_TEXT_WAVES
+#endif
+#ifdef LZS_EXP_TEXT_LEAN
+#define LZS_WGV_LEAN 1
+#endif
+#ifdef LZS_EXP_TEXT_WG_WAVES
+#define LZS_WGV_WG_WAVES LZS_EXP_TEXT_WG_WAVES
+#endif
+#ifdef LZS_EXP_TEXT_HEAD2
+#define LZS_WGV_HEAD2 LZS_EXP_TEXT_HEAD2
+#endif
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_safe {
@@ -334,7 +346,7 @@ static int verify_launch(void *d_out, size_t out_stride, uint32_t out_cap, uint3
     if (e == hipSuccess) e = hipMalloc((void **)&d_len2, sizeof(uint32_t) * ((size_t)nblocks + 1));
     if (e == hipSuccess) e = hipMemsetAsync(d_len2 + nblocks, 0, sizeof(uint32_t), stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(wgv_safe::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0, stream, d_scratch, stride, out_cap, d_len2,
+        hipLaunchKernelGGL(wgv_safe::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(wgv_safe::kWgThreads), 0, stream, d_scratch, stride, out_cap, d_len2,
                            (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 0u);
         hipLaunchKernelGGL(lzs_verify_slots_kernel, dim3(nblocks), dim3(256), 0, stream, (const uint8_t *)d_out, (const uint32_t *)d_out_len,
                            (const uint8_t *)d_scratch, (const uint32_t *)d_len2, out_stride, stride, nblocks, d_len2 + nblocks);
@@ -388,7 +400,7 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
         return !v ? 0 : (v[0] == 't' ? 1 : (v[0] == 'f' ? 2 : (v[0] == 'l' ? 3 : 0)));
     }();
 #define LZS_LAUNCH_VARIANT(ns, serve) \
-    hipLaunchKernelGGL(ns::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(kWgThreads), 0, (hipStream_t)stream, (uint8_t *)d_out, out_stride, \
+    hipLaunchKernelGGL(ns::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(ns::kWgThreads), 0, (hipStream_t)stream, (uint8_t *)d_out, out_stride, \
                        out_cap, d_out_len, (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, serve)
     if (chain_mode != 0) LZS_LAUNCH_VARIANT(wgv_safe, 0u);
 #ifndef LZS_ONE_VARIANT
@@ -508,12 +520,12 @@ int lzs_hip_launch_compress_segments(void *d_slots, size_t slot_stride, const vo
     int chain_mode = 0;
     { const int e = lzs_hip_chain_mode(stream, &chain_mode); if (e) return e; }
     if (chain_mode != 0)
-        hipLaunchKernelGGL(wgv_safe::lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(wgv_safe::lzs_compress_segments_kernel, dim3(nseg), dim3(wgv_safe::kWgThreads), 0, (hipStream_t)stream,
                            (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
                            d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
                            (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open);
     else
-        hipLaunchKernelGGL(wgv_text::lzs_compress_segments_kernel, dim3(nseg), dim3(kWgThreads), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(wgv_text::lzs_compress_segments_kernel, dim3(nseg), dim3(wgv_text::kWgThreads), 0, (hipStream_t)stream,
                            (uint8_t *)d_slots, slot_stride, (const uint8_t *)d_in, n, seg, nseg,
                            d_entry, d_dirty, d_exit, (unsigned long long *)d_nbits,
                            (uint8_t *)d_out, (const unsigned long long *)d_bit_at, lim, d_open);
