@@ -66,7 +66,8 @@ def lib() -> ctypes.CDLL:
             f = getattr(L, name)
             f.restype, f.argtypes = _sz, [_vp, _sz, _vp, _sz]
         L.lzs_last_error.restype, L.lzs_last_error.argtypes = ctypes.c_char_p, []
-        L.lzs_release_thread_cache.restype, L.lzs_release_thread_cache.argtypes = None, []
+        if hasattr(L, "lzs_release_thread_cache"):      # (an older build named by LZS_LIBRARY, for A/B runs, has none)
+            L.lzs_release_thread_cache.restype, L.lzs_release_thread_cache.argtypes = None, []
         L.lzs_backend_info.restype, L.lzs_backend_info.argtypes = ctypes.c_int, [ctypes.c_char_p, _sz]
         for name in ("lzs_compress_batch_device", "lzs_decompress_batch_device"):
             f = getattr(L, name)

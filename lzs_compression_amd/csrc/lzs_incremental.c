@@ -14,6 +14,7 @@ typedef struct __attribute__((packed)) {
     uint16_t hist_len;              /* bytes in hist[], oldest first */
     uint8_t  qlen, rem, extended;   /* bits in bitq; copy bytes left; a length nibble follows */
     uint8_t  hist[LZS_MAX_HISTORY_SIZE];
+    uint8_t  big_log;               /* how much input a pass of the many-wavefront path takes: 1 MiB << big_log (learnt over the calls) */
 } dec_priv_t;
 #define DEC_PRIV_AT 36u
 #define DEC_SMALL     16384u        /* calls up to this much input and output take the short way */
@@ -105,8 +106,11 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
     /* how much input one pass of the many-wavefront path looks at: it scans ALL of it but decodes
      * only up to the first end marker, so a buffer of concatenated streams (what lzs-compress
      * writes with -b) would be scanned once per marker in full; starts small, doubles only while
-     * the pass before was used up to its end */
-    size_t big_limit = (size_t)1 << 20;
+     * the pass before was used up to its end
+     * (round 6) ... and what was learnt stays in the block for the next call: a stream without early markers that is fed in
+     * pieces of 16 MiB is decoded in one pass a piece, not in five (1 + 2 + 4 + 8 + 1 MiB, each with its scan, decode and
+     * resolve rounds: 12 ms for an 8 MiB piece, profiles/r06/inc_dec_stages.txt) */
+    size_t big_limit = (size_t)1 << (20u + (pv->big_log <= 8u ? pv->big_log : 0u));
     for (;;) {
         /* A large piece first goes to many wavefronts (stream_decompress) as far as
          * whole segments can be decoded; what is left -- the segment with the end marker, the
@@ -149,7 +153,13 @@ size_t lzs_decompress_incremental(LzsDecompressParameters_t *p)
                     pv->hist_len = (uint16_t)(keep + got);
                 }
                 const size_t used = at - nb + (b ? 1u : 0u);
-                if (used + 4u * (size_t)dp.seg >= big && big_limit < ((size_t)256 << 20)) big_limit *= 2;
+                if (used + 4u * (size_t)dp.seg >= big) {
+                    /* used up to its end: the next pass may take twice as much -- if this one was cut by its limit, not by the piece */
+                    if (big == big_limit && big_limit < ((size_t)256 << 20)) { big_limit *= 2; pv->big_log++; }
+                } else if (used < big / 4u && pv->big_log > 0u) {
+                    /* an end marker early in the pass (concatenated streams): scan less next time */
+                    big_limit /= 2; pv->big_log--;
+                }
                 p->inPtr += used;  p->inLength -= used;
                 p->outPtr += got;  p->outLength -= got;
                 made += got;
