@@ -84,6 +84,19 @@ namespace wgv_safe {
 #define LZS_WGV_PRIO 1
 #include "kernels/compress_wg.inc"
 }
+#ifdef LZS_WITH_VARIANTS      // liblzs_variants.so only (LZS_KERNEL=wg8 | p256): round 6's two other shapes of the default kernel, kept
+namespace wgv_text8 {         // under test as parameters of kernels/compress_wg.inc -- eight waves per workgroup (pools of 1024) ...
+#define LZS_WGV_PRIO 1
+#define LZS_WGV_WG_WAVES 8
+#define LZS_WGV_WAVES 6
+#include "kernels/compress_wg.inc"
+}
+namespace wgv_pool256 {       // ... and pools of 256 positions (one chunk per wave)
+#define LZS_WGV_PRIO 1
+#define LZS_WGV_POOL 256
+#include "kernels/compress_wg.inc"
+}
+#endif
 #ifndef LZS_ONE_VARIANT      // (tools/probes/ab.sh -DLZS_ONE_VARIANT: the default alone, for the probes that launch it directly)
 // Round 6: NEITHER of the two keeps a 3-byte chain (LZS_WGV_NO3: every position walks the 2-byte chain with the full rule, which is
 // exact for any block -- that chain is complete for every match of 2 and more).  Where grams do not repeat the 3-byte chain holds
@@ -376,8 +389,17 @@ int lzs_hip_launch_compress(void *d_out, size_t out_stride, uint32_t out_cap, ui
     // A/B builds only: LZS_KERNEL=chain (one wave per block) | scan (brute force) select the earlier kernels
     static const int variant = [] {
         const char *v = getenv("LZS_KERNEL");
-        return !v ? 0 : (v[0] == 's' ? 2 : (v[0] == 'c' ? 1 : 0));
+        return !v ? 0 : (v[0] == 's' ? 2 : (v[0] == 'c' ? 1 : (v[0] == 'w' ? 3 : (v[0] == 'p' ? 4 : 0))));
     }();
+    if (variant == 3 || variant == 4) {        // the default kernel in its two other shapes (round 6)
+        if (variant == 3)
+            hipLaunchKernelGGL(wgv_text8::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(wgv_text8::kWgThreads), 0, (hipStream_t)stream, (uint8_t *)d_out,
+                               out_stride, out_cap, d_out_len, (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 0u);
+        else
+            hipLaunchKernelGGL(wgv_pool256::lzs_compress_blocks_wg_kernel, dim3(nblocks), dim3(wgv_pool256::kWgThreads), 0, (hipStream_t)stream, (uint8_t *)d_out,
+                               out_stride, out_cap, d_out_len, (const uint8_t *)d_in, in_stride, d_in_len, in_len, nblocks, 0u);
+        return (int)hipGetLastError();
+    }
     if (variant == 2) {
         hipLaunchKernelGGL(lzs_compress_blocks_scan_kernel, dim3(grid), dim3(kWavesPerWG * 64), 0,
                            (hipStream_t)stream, (uint8_t *)d_out, out_stride, out_cap, d_out_len,

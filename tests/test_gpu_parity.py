@@ -1080,19 +1080,41 @@ def _run_with(code, **extra_env):
     return r.stdout.strip()
 
 
-@pytest.mark.parametrize("variant", ["chain", "scan"])
+@pytest.mark.parametrize("variant", ["chain", "scan", "wg8", "p256"])
 def test_other_compress_kernels_agree(variant):
     """liblzs_variants.so (the library built once more with the earlier kernels, tests and A/B only)
     with LZS_KERNEL=chain|scan -- one wavefront per block / brute force over all offsets, independent
-    implementations of the same rule -- gives the bytes of the product library."""
+    implementations of the same rule -- gives the bytes of the product library; and so do the default kernel's
+    two other shapes that kernels/compress_wg.inc takes as parameters (round 6: LZS_KERNEL=wg8, eight waves per
+    workgroup with pools of 1024; p256, pools of 256) -- on the three classes, and on ragged blocks of runs, periods,
+    text and noise with cut capacities (open matches, run mode, the last partial pool, capacity stops)."""
     code = (
-        "import numpy as np, hashlib, lzs_compression_amd as lzs\n"
+        "import numpy as np, hashlib, random, lzs_compression_amd as lzs\n"
         "from lzs_compression_amd import workload\n"
         "h = hashlib.sha256()\n"
         "for cls in workload.CLASS_NAMES:\n"
         "    out, n = lzs.compress_batch(workload.fill(cls, 24))\n"
         "    for b in range(24): h.update(out[b, :n[b]].tobytes())\n"
+        "rng = random.Random(606)\n"
+        "text = workload.fill('text', 8).tobytes()\n"
+        "rows = np.zeros((40, 70000), dtype=np.uint8); lens = np.zeros(40, dtype=np.uint32)\n"
+        "for b in range(40):\n"
+        "    d = bytearray()\n"
+        "    want = rng.choice((0, 1, 2, 13, 100, 511, 512, 513, 1023, 1024, 1025, 4096, 20000, 65535, 65536, 70000))\n"
+        "    while len(d) < want:\n"
+        "        k = rng.randint(0, 4)\n"
+        "        if k == 0: d += bytes([rng.randint(0, 255)]) * rng.randint(1, 9000)\n"
+        "        elif k == 1: a = rng.randint(0, len(text) - 2); d += text[a:a + rng.randint(1, 30000)]\n"
+        "        elif k == 2: d += rng.randbytes(rng.randint(1, 3000))\n"
+        "        elif k == 3: u = rng.randbytes(rng.randint(1, 2500)); d += u * rng.randint(1, 30)\n"
+        "        else: d += bytes(rng.choice(b'ab') for _ in range(rng.randint(1, 300)))\n"
+        "    d = bytes(d[:want]); rows[b, :len(d)] = np.frombuffer(d, dtype=np.uint8); lens[b] = len(d)\n"
+        "for cap in (None, 3000, 7):\n"
+        "    out, n = lzs.compress_batch(rows, lens, cap)\n"
+        "    h.update(n.tobytes())\n"
+        "    for b in range(40): h.update(out[b, :n[b]].tobytes())\n"
         "print(h.hexdigest())\n")
+    # (LZS_ONE_WAVE... is not needed: a host batch of this size is one launch of the block kernel either way)
     assert _run_with(code) == _run_with(code, LZS_LIBRARY=VARIANTS_SO, LZS_KERNEL=variant)
 
 
