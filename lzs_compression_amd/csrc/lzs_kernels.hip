@@ -56,25 +56,39 @@ namespace {
 namespace wgv_text {
 #define LZS_WGV_SEGMENTS 1
 #define LZS_WGV_PRIO 1
-// (six workgroups per CU for THIS variant cost more in buckets than the sixth workgroup gives: 1024 / 512 buckets 72.6 GB/s,
-// 896 / 512 71.5, 1152 / 256 70.3, 768 / 1024 69.0 against 74.7 -- profiles/r05/ab_s41)
-#ifdef LZS_EXP_TEXT_POOL     // (tools/probes/ab.sh: round 6's pool of 256 and its bucket counts, profiles/r06/ab_s3)
-#define LZS_WGV_POOL LZS_EXP_TEXT_POOL
+// Round 6: SIX workgroups per CU.  A sixth workgroup is +8.9 % at equal work (profiles/r06/ab_s19) and until now cost more in buckets
+// than it gave (1792 / 1024 -> 1024 / 512: -9.5 %; round 5's ab_s41: 72.6 against 74.7) -- with multipliers that spread a text's
+// grams (kernels/compress_wg.inc, tools/sim/hash_sim.c) the smaller tables have FEWER collisions than the large ones had:
+// 26.7 KB of LDS, SEARCH's constants as literals and the allocation held to 80 registers.  profiles/r06/ab_s31 ... ab_s34:
+// 74.6 -> 76.8 (the multipliers alone, 1792 / 1024, five workgroups) -> 79.1 GB/s (1024 / 512 buckets, six).
+#ifndef LZS_EXP_TEXT_HEAD3
+#define LZS_EXP_TEXT_HEAD3 1024
 #endif
-#ifdef LZS_EXP_TEXT_HEAD3
+#ifndef LZS_EXP_TEXT_HEAD2
+#define LZS_EXP_TEXT_HEAD2 512
+#endif
+#ifndef LZS_EXP_TEXT_WAVES
+#define LZS_EXP_TEXT_WAVES 6
+#endif
 #define LZS_WGV_HEAD3 LZS_EXP_TEXT_HEAD3
-#endif
-#ifdef LZS_EXP_TEXT_WAVES
+#define LZS_WGV_HEAD2 LZS_EXP_TEXT_HEAD2
+#if LZS_EXP_TEXT_WAVES > 0
 #define LZS_WGV_WAVES LZS_EXP_TEXT_WAVES
 #endif
-#ifdef LZS_EXP_TEXT_LEAN
+#ifndef LZS_EXP_TEXT_NOT_LEAN
 #define LZS_WGV_LEAN 1
+#endif
+#ifndef LZS_HASH3_MUL         // (the best of 8000 for 1024 / 512 buckets; -DLZS_HASH3_MUL= / -DLZS_HASH2_MUL= override: tools/probes/ab.sh)
+#define LZS_WGV_HASH3_MUL 0x444D91u
+#endif
+#ifndef LZS_HASH2_MUL
+#define LZS_WGV_HASH2_MUL 0x64EBAD33u
+#endif
+#ifdef LZS_EXP_TEXT_POOL      // (tools/probes/ab.sh: round 6's pool of 256, profiles/r06/ab_s3)
+#define LZS_WGV_POOL LZS_EXP_TEXT_POOL
 #endif
 #ifdef LZS_EXP_TEXT_WG_WAVES
 #define LZS_WGV_WG_WAVES LZS_EXP_TEXT_WG_WAVES
-#endif
-#ifdef LZS_EXP_TEXT_HEAD2
-#define LZS_WGV_HEAD2 LZS_EXP_TEXT_HEAD2
 #endif
 #include "kernels/compress_wg.inc"
 }
