@@ -79,7 +79,7 @@ namespace wgv_text {
 #define LZS_WGV_LEAN 1
 #endif
 #ifndef LZS_HASH3_MUL         // (the best of 8000 for 1024 / 512 buckets; -DLZS_HASH3_MUL= / -DLZS_HASH2_MUL= override: tools/probes/ab.sh)
-#define LZS_WGV_HASH3_MUL 0x444D91u
+#define LZS_WGV_HASH3_MUL 0x897397u
 #endif
 #ifndef LZS_HASH2_MUL
 #define LZS_WGV_HASH2_MUL 0x64EBAD33u

@@ -90,14 +90,21 @@ int main(int argc, char **argv)
     if (getenv("HASH_SIM_M3")) { const uint32_t m = (uint32_t)strtoul(getenv("HASH_SIM_M3"), NULL, 0); printf("  3-byte table, multiplier 0x%06X: %.3f\n", m, count(1, m) / per); }
     if (getenv("HASH_SIM_M2")) { const uint32_t m = (uint32_t)strtoul(getenv("HASH_SIM_M2"), NULL, 0); printf("  2-byte table, multiplier 0x%08X: %.3f\n", m, count(0, m) / per); }
     uint64_t x = 0x9E3779B97F4A7C15ull;
-    uint32_t best3 = 0, best2 = 0; unsigned long long c3 = ~0ull, c2 = ~0ull;
+    enum { TOP = 6 };
+    uint32_t best3[TOP] = {0}, best2[TOP] = {0}; unsigned long long c3[TOP], c2[TOP];
+    for (int i = 0; i < TOP; i++) c3[i] = c2[i] = ~0ull;
     for (unsigned i = 0; i < ncand; i++) {
         x ^= x << 13; x ^= x >> 7; x ^= x << 17;
         const uint32_t m3 = ((uint32_t)(x >> 20) & 0xFFFFFFu) | 1u, m2 = (uint32_t)(x >> 8) | 1u;
         const unsigned long long a = count(1, m3), c = count(0, m2);
-        if (a < c3) { c3 = a; best3 = m3; }
-        if (c < c2) { c2 = c; best2 = m2; }
+        for (int k = 0; k < TOP; k++) if (a < c3[k]) { for (int j = TOP - 1; j > k; j--) { c3[j] = c3[j - 1]; best3[j] = best3[j - 1]; } c3[k] = a; best3[k] = m3; break; }
+        for (int k = 0; k < TOP; k++) if (c < c2[k]) { for (int j = TOP - 1; j > k; j--) { c2[j] = c2[j - 1]; best2[j] = best2[j - 1]; } c2[k] = c; best2[k] = m2; break; }
     }
-    printf("  best of %u random odd multipliers: 3-byte 0x%06X: %.3f; 2-byte 0x%08X: %.3f\n", ncand, best3, c3 / per, best2, c2 / per);
+    printf("  best of %u random odd multipliers: 3-byte 0x%06X: %.3f; 2-byte 0x%08X: %.3f\n", ncand, best3[0], c3[0] / per, best2[0], c2[0] / per);
+    printf("  the next:");
+    for (int k = 1; k < TOP; k++) printf(" 0x%06X %.3f", best3[k], c3[k] / per);
+    printf(" |");
+    for (int k = 1; k < TOP; k++) printf(" 0x%08X %.3f", best2[k], c2[k] / per);
+    printf("\n");
     return 0;
 }
