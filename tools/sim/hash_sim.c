@@ -90,7 +90,7 @@ int main(int argc, char **argv)
     if (getenv("HASH_SIM_M3")) { const uint32_t m = (uint32_t)strtoul(getenv("HASH_SIM_M3"), NULL, 0); printf("  3-byte table, multiplier 0x%06X: %.3f\n", m, count(1, m) / per); }
     if (getenv("HASH_SIM_M2")) { const uint32_t m = (uint32_t)strtoul(getenv("HASH_SIM_M2"), NULL, 0); printf("  2-byte table, multiplier 0x%08X: %.3f\n", m, count(0, m) / per); }
     uint64_t x = 0x9E3779B97F4A7C15ull;
-    enum { TOP = 6 };
+    enum { TOP = 16 };
     uint32_t best3[TOP] = {0}, best2[TOP] = {0}; unsigned long long c3[TOP], c2[TOP];
     for (int i = 0; i < TOP; i++) c3[i] = c2[i] = ~0ull;
     for (unsigned i = 0; i < ncand; i++) {
