@@ -351,6 +351,39 @@ def test_large_pieces_decode_through_many_wavefronts(route):
         assert got == want and markers == len(plains), (ilo, ihi, olo, ohi, len(got), markers)
 
 
+def test_pieces_of_several_mib_and_the_pass_size_the_block_remembers(route):
+    """Round 6: how much input one pass of the many-wavefront path takes is kept in the caller's block (1 MiB doubling while
+    passes are used up to their end, halving when an end marker comes early), so a stream fed in pieces of several MiB is
+    decoded in one pass a piece.  One stream of 40 MiB of text in pieces of 4 MiB and of 1.5 - 6 MiB (the size grows), then
+    -- on the SAME block, after the marker -- sixty short streams back to back in one piece (markers early in every pass: the size
+    shrinks again), then the long stream once more; every byte against the input."""
+    device_only(route)
+    rng = random.Random(77)
+    big = _sample("text", 40 << 20)
+    sbig = lzs.compress(big)
+    shorts = [_sample("text", rng.randint(20000, 200000), seed=9 + i) for i in range(60)]
+    sshort = b"".join(O.compress(x) for x in shorts)
+    d = lzs.IncrementalDecompressor()
+
+    def feed(stream, sizes, room):
+        out, pos = bytearray(), 0
+        while pos < len(stream):
+            pending = stream[pos:pos + next(sizes)]
+            pos += len(pending)
+            for _ in range(100000):
+                got, used, status = d.step(pending, room)
+                out += got
+                pending = pending[used:]
+                assert not (status & lzs.STATUS_ERROR)
+                if not pending:
+                    break
+        return bytes(out)
+
+    assert feed(sbig, _const(4 << 20), 16 << 20) == big
+    assert feed(sshort, _const(len(sshort)), 64 << 20) == b"".join(shorts)
+    assert feed(sbig, _rand(rng, 3 << 19, 6 << 20), 8 << 20) == big
+
+
 def test_no_large_piece_is_left_to_one_wavefront(route):
     """A copy still running when a call returns must not send the whole next piece to the one wavefront (round 4: half
     a MiB took 176 ms that way, one piece in fifty, against 0.7 ms for the others).  Sixty pieces of 256 KiB of one
