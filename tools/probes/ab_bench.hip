@@ -5,6 +5,7 @@
 #include KSRC
 #include <vector>
 #include <string>
+#include <cstring>
 #ifdef AB_VIA_LAUNCHER   // the library's own launcher: the classifier and one variant of the kernel per class (LZS_VARIANT=text|few|lit forces one)
 #define AB_LAUNCH(nb, d_out, stride, d_len, d_in, bl) lzs_hip_launch_compress(d_out, stride, 73731u, d_len, d_in, bl, nullptr, bl, nb, nullptr)
 #endif
@@ -21,7 +22,17 @@ int main(int argc, char **argv)
     std::vector<uint8_t> h((size_t)nb * bl);
     const std::string cache = "/tmp/lzs_ab_class" + std::to_string(cls) + "_" + std::to_string(nb) + ".bin";
     bool have = false;
-    if (FILE *f = fopen(cache.c_str(), "rb")) { have = fread(h.data(), 1, h.size(), f) == h.size(); fclose(f); }
+    if (!getenv("AB_FILE")) if (FILE *f = fopen(cache.c_str(), "rb")) { have = fread(h.data(), 1, h.size(), f) == h.size(); fclose(f); }
+    // AB_FILE=path: the blocks are the file's 64 KiB pieces, over and over (real text from the build container, say: is a choice tuned
+    // on the seeded classes one for other data of the kind as well?) -- not cached
+    if (const char *path = getenv("AB_FILE")) {
+        std::vector<uint8_t> f;
+        if (FILE *fp = fopen(path, "rb")) { uint8_t buf[65536]; size_t k; while ((k = fread(buf, 1, sizeof buf, fp)) > 0) f.insert(f.end(), buf, buf + k); fclose(fp); }
+        const size_t pieces = f.size() / bl;
+        if (!pieces) { fprintf(stderr, "AB_FILE: fewer than 64 KiB\n"); return 2; }
+        for (uint32_t b = 0; b < nb; b++) memcpy(h.data() + (size_t)b * bl, f.data() + (b % pieces) * bl, bl);
+        have = true;
+    }
     if (!have) {
         lzs_workload_fill(h.data(), cls, 0x4C5A5331ull, 0, nb, bl, 32);
         if (FILE *f = fopen((cache + ".tmp").c_str(), "wb")) { const bool ok = fwrite(h.data(), 1, h.size(), f) == h.size(); fclose(f); if (ok) rename((cache + ".tmp").c_str(), cache.c_str()); }
