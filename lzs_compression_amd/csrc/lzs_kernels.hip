@@ -56,13 +56,18 @@ namespace {
 namespace wgv_text {
 #define LZS_WGV_SEGMENTS 1
 #define LZS_WGV_PRIO 1
+#ifndef LZS_EXP_TEXT_EXIT16
+#define LZS_WGV_EXIT8 1
+#endif
 // Round 6: SIX workgroups per CU.  A sixth workgroup is +8.9 % at equal work (profiles/r06/ab_s19) and until now cost more in buckets
 // than it gave (1792 / 1024 -> 1024 / 512: -9.5 %; round 5's ab_s41: 72.6 against 74.7) -- with multipliers that spread a text's
 // grams (kernels/compress_wg.inc, tools/sim/hash_sim.c) the smaller tables have FEWER collisions than the large ones had:
 // 26.7 KB of LDS, SEARCH's constants as literals and the allocation held to 80 registers.  profiles/r06/ab_s31 ... ab_s34:
 // 74.6 -> 76.8 (the multipliers alone, 1792 / 1024, five workgroups) -> 79.1 GB/s (1024 / 512 buckets, six).
+// 1152 three-byte buckets since PARSE's exit functions are one byte a position (26 720 B; 26 848 is the most six workgroups leave
+// each other): 3.52 candidates a walk visits instead of 3.74, +0.6 ... 1.0 % (profiles/r06/ab_s48).
 #ifndef LZS_EXP_TEXT_HEAD3
-#define LZS_EXP_TEXT_HEAD3 1024
+#define LZS_EXP_TEXT_HEAD3 1152
 #endif
 #ifndef LZS_EXP_TEXT_HEAD2
 #define LZS_EXP_TEXT_HEAD2 512
@@ -78,7 +83,7 @@ namespace wgv_text {
 #ifndef LZS_EXP_TEXT_NOT_LEAN
 #define LZS_WGV_LEAN 1
 #endif
-#ifndef LZS_HASH3_MUL         // (the best of 8000 for 1024 / 512 buckets; -DLZS_HASH3_MUL= / -DLZS_HASH2_MUL= override: tools/probes/ab.sh)
+#ifndef LZS_HASH3_MUL         // (the best of 8000 for 1024 / 512 buckets and of 6000 for 1152 / 512; -DLZS_HASH3_MUL= / -DLZS_HASH2_MUL= override: tools/probes/ab.sh)
 #define LZS_WGV_HASH3_MUL 0x897397u
 #endif
 #ifndef LZS_HASH2_MUL
@@ -103,6 +108,7 @@ namespace wgv_text8 {         // under test as parameters of kernels/compress_wg
 #define LZS_WGV_PRIO 1
 #define LZS_WGV_WG_WAVES 8
 #define LZS_WGV_WAVES 6
+#define LZS_WGV_EXIT8 1
 #include "kernels/compress_wg.inc"
 }
 namespace wgv_pool256 {       // ... and pools of 256 positions (one chunk per wave)
