@@ -971,7 +971,7 @@ def single(args) -> int:
                      "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic if traffic else traffic_note,
                      "kernel": "lzs_compress_blocks_wg_kernel",
                      "kernel_note": "one launch = lzs_classify_blocks_kernel + the kernel's variant for each class of block over the same "
-                                    "grid (wgv_text the default, wgv_few small tables / six workgroups per CU, wgv_lit one full step per pass; "
+                                    "grid (wgv_text the default at six workgroups per CU, wgv_few and wgv_lit without a 3-byte chain at eight; "
                                     "a workgroup whose block is another variant's returns at once): the events bracket all of them",
                      "algorithmic_bytes_per_launch": {"read_input": in_bytes,
                                                       "total_read_plus_written": algo_bytes},
